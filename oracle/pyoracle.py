@@ -1,0 +1,230 @@
+"""ctypes loader for oracle/liboracle.so (built by oracle/Makefile).
+
+TEST INFRASTRUCTURE: the checker for the HIP engine, never the thing shipped.
+Each wrapper names the reference function it restates; the C file carries the
+file:line citations.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+VOTE_PENDING, VOTE_LOST, VOTE_WON = 1, 2, 3
+VOTE_NAMES = {1: "VotePending", 2: "VoteLost", 3: "VoteWon"}
+
+ACK_DTYPE = np.dtype([("group", "<u4"), ("slot", "<u4"), ("index", "<u8")])
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liboracle.so")
+    src = os.path.join(_HERE, "quorum_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(so):
+            build()
+        L = C.CDLL(so)
+        u64p, vp, u8p = C.POINTER(C.c_uint64), C.c_void_p, C.POINTER(C.c_uint8)
+        L.oracle_majority_committed_index.restype = C.c_uint64
+        L.oracle_majority_committed_index.argtypes = [u64p, C.c_int, u64p, u64p, C.c_int]
+        L.oracle_alt_majority_committed_index.restype = C.c_uint64
+        L.oracle_alt_majority_committed_index.argtypes = [u64p, C.c_int, u64p, u64p, C.c_int]
+        L.oracle_joint_committed_index.restype = C.c_uint64
+        L.oracle_joint_committed_index.argtypes = [u64p, C.c_int, u64p, C.c_int, u64p, u64p, C.c_int]
+        L.oracle_majority_vote_result.restype = C.c_int
+        L.oracle_majority_vote_result.argtypes = [u64p, C.c_int, u64p, u64p, C.c_int]
+        L.oracle_joint_vote_result.restype = C.c_int
+        L.oracle_joint_vote_result.argtypes = [u64p, C.c_int, u64p, C.c_int, u64p, u64p, C.c_int]
+        L.oracle_maybe_update.restype = C.c_int
+        L.oracle_maybe_update.argtypes = [u64p, u64p, C.c_uint64]
+        L.oracle_log_maybe_commit.restype = C.c_uint64
+        L.oracle_log_maybe_commit.argtypes = [C.c_uint64] * 4
+        L.oracle_batch_committed.restype = None
+        L.oracle_batch_committed.argtypes = [C.c_uint64, C.c_int, vp, C.c_uint64, vp, vp, C.c_int,
+                                             C.c_int, vp, C.c_int]
+        L.oracle_batch_tally_votes.restype = None
+        L.oracle_batch_tally_votes.argtypes = [C.c_uint64, C.c_int, vp, C.c_uint64, vp, vp, vp,
+                                               C.c_int, C.c_int, vp, vp, vp]
+        L.oracle_batch_quorum_active.restype = None
+        L.oracle_batch_quorum_active.argtypes = [C.c_uint64, C.c_int, vp, vp, vp, vp, C.c_int,
+                                                 C.c_int, vp]
+        L.oracle_batch_ack_quorum.restype = None
+        L.oracle_batch_ack_quorum.argtypes = [C.c_uint64, C.c_int, vp, vp, vp, C.c_int, C.c_int, vp]
+        L.oracle_scatter_acks.restype = C.c_uint64
+        L.oracle_scatter_acks.argtypes = [C.c_uint64, C.c_int, vp, C.c_uint64, vp, C.c_uint64]
+        L.oracle_bench_create.restype = C.c_void_p
+        L.oracle_bench_create.argtypes = [C.c_uint64, C.c_int, vp, C.c_uint64]
+        L.oracle_bench_run.restype = C.c_int
+        L.oracle_bench_run.argtypes = [C.c_void_p, vp, C.c_int]
+        L.oracle_bench_destroy.restype = None
+        L.oracle_bench_destroy.argtypes = [C.c_void_p]
+        _LIB = L
+    return _LIB
+
+
+def _arr(xs):
+    a = np.ascontiguousarray(np.asarray(list(xs), dtype=np.uint64))
+    return a, a.ctypes.data_as(C.POINTER(C.c_uint64)), len(a)
+
+
+def _map(m):
+    ids, pi, n = _arr(m.keys())
+    vals, pv, _ = _arr(int(v) for v in m.values())
+    return (ids, vals), pi, pv, n
+
+
+# ---- per-group, id-level (the reference's own shapes) ----------------------
+
+def majority_committed_index(cfg, l):
+    """MajorityConfig(cfg).CommittedIndex(mapAckIndexer(l))."""
+    c, pc, n = _arr(cfg)
+    keep, pi, pv, ln = _map(l)
+    return int(lib().oracle_majority_committed_index(pc, n, pi, pv, ln))
+
+
+def alt_majority_committed_index(cfg, l):
+    """alternativeMajorityCommittedIndex (quorum/quick_test.go)."""
+    c, pc, n = _arr(cfg)
+    keep, pi, pv, ln = _map(l)
+    return int(lib().oracle_alt_majority_committed_index(pc, n, pi, pv, ln))
+
+
+def joint_committed_index(cfg0, cfg1, l):
+    """JointConfig{cfg0,cfg1}.CommittedIndex(mapAckIndexer(l))."""
+    c0, p0, n0 = _arr(cfg0)
+    c1, p1, n1 = _arr(cfg1)
+    keep, pi, pv, ln = _map(l)
+    return int(lib().oracle_joint_committed_index(p0, n0, p1, n1, pi, pv, ln))
+
+
+def majority_vote_result(cfg, votes):
+    """MajorityConfig(cfg).VoteResult(votes); votes: id -> bool."""
+    c, pc, n = _arr(cfg)
+    keep, pi, pv, vn = _map(votes)
+    return int(lib().oracle_majority_vote_result(pc, n, pi, pv, vn))
+
+
+def joint_vote_result(cfg0, cfg1, votes):
+    """JointConfig{cfg0,cfg1}.VoteResult(votes)."""
+    c0, p0, n0 = _arr(cfg0)
+    c1, p1, n1 = _arr(cfg1)
+    keep, pi, pv, vn = _map(votes)
+    return int(lib().oracle_joint_vote_result(p0, n0, p1, n1, pi, pv, vn))
+
+
+def maybe_update(match, nxt, n):
+    """Progress{Match,Next}.MaybeUpdate(n) -> (updated, match, next)."""
+    m, x = C.c_uint64(match), C.c_uint64(nxt)
+    ok = lib().oracle_maybe_update(C.byref(m), C.byref(x), n)
+    return bool(ok), m.value, x.value
+
+
+def log_maybe_commit(committed, max_index, term_of_max, term):
+    """raftLog.maybeCommit guard -> new committed."""
+    return int(lib().oracle_log_maybe_commit(committed, max_index, term_of_max, term))
+
+
+# ---- batched SoA views ------------------------------------------------------
+
+def _vp(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _mask_bytes(*masks):
+    for m in masks:
+        if m is not None:
+            return m.dtype.itemsize
+    return 1
+
+
+def _chk(a, dtype=None):
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"]
+    if dtype is not None:
+        assert a.dtype == dtype, (a.dtype, dtype)
+    return a
+
+
+def batch_committed(match, in_mask=None, out_mask=None, uniform_voters=0, threads=1):
+    """ProgressTracker.Committed for every group. match: u64 [S][G]."""
+    match = _chk(match, np.uint64)
+    S, G = match.shape
+    out = np.empty(G, dtype=np.uint64)
+    lib().oracle_batch_committed(G, S, _vp(match), match.strides[0] // 8, _vp(_chk(in_mask)),
+                                 _vp(_chk(out_mask)), _mask_bytes(in_mask, out_mask),
+                                 uniform_voters, _vp(out), threads)
+    return out
+
+
+def batch_tally_votes(votes, in_mask=None, out_mask=None, learner_mask=None, uniform_voters=0):
+    """ProgressTracker.TallyVotes for every group -> (result, granted, rejected)."""
+    votes = _chk(votes, np.uint8)
+    S, G = votes.shape
+    res = np.empty(G, dtype=np.uint8)
+    gr = np.empty(G, dtype=np.uint8)
+    rj = np.empty(G, dtype=np.uint8)
+    lib().oracle_batch_tally_votes(G, S, _vp(votes), votes.strides[0], _vp(_chk(in_mask)),
+                                   _vp(_chk(out_mask)), _vp(_chk(learner_mask)),
+                                   _mask_bytes(in_mask, out_mask, learner_mask), uniform_voters,
+                                   _vp(res), _vp(gr), _vp(rj))
+    return res, gr, rj
+
+
+def batch_quorum_active(active, nslots, in_mask=None, out_mask=None, learner_mask=None,
+                        uniform_voters=0):
+    """ProgressTracker.QuorumActive for every group -> u8 bool."""
+    active = _chk(active)
+    G = active.shape[0]
+    out = np.empty(G, dtype=np.uint8)
+    lib().oracle_batch_quorum_active(G, nslots, _vp(active), _vp(_chk(in_mask)),
+                                     _vp(_chk(out_mask)), _vp(_chk(learner_mask)),
+                                     active.dtype.itemsize, uniform_voters, _vp(out))
+    return out
+
+
+def batch_ack_quorum(acks, nslots, in_mask=None, out_mask=None, uniform_voters=0):
+    """Voters.VoteResult(readOnly acks) for every group -> VoteResult u8."""
+    acks = _chk(acks)
+    G = acks.shape[0]
+    out = np.empty(G, dtype=np.uint8)
+    lib().oracle_batch_ack_quorum(G, nslots, _vp(acks), _vp(_chk(in_mask)), _vp(_chk(out_mask)),
+                                  acks.dtype.itemsize, uniform_voters, _vp(out))
+    return out
+
+
+def scatter_acks(match, recs):
+    """Apply MsgAppResp acks in order (Progress.MaybeUpdate); mutates match. Returns #skipped."""
+    match = _chk(match, np.uint64)
+    recs = _chk(recs, ACK_DTYPE)
+    S, G = match.shape
+    return int(lib().oracle_scatter_acks(G, S, _vp(match), match.strides[0] // 8, _vp(recs),
+                                         len(recs)))
+
+
+class CpuBaseline:
+    """bench.py cpu_baseline leg: per-group id set + id-keyed map, parallel loop."""
+
+    def __init__(self, match, V):
+        match = _chk(match, np.uint64)
+        self.G = match.shape[1]
+        self.h = lib().oracle_bench_create(self.G, V, _vp(match), match.strides[0] // 8)
+        self.out = np.empty(self.G, dtype=np.uint64)
+
+    def run(self, threads):
+        return lib().oracle_bench_run(self.h, _vp(self.out), threads)
+
+    def close(self):
+        if self.h:
+            lib().oracle_bench_destroy(self.h)
+            self.h = None

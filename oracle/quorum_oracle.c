@@ -1,0 +1,553 @@
+/*
+ * quorum_oracle.c — CPU restatement of the reference's quorum / tracker hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This file is the parity checker for the HIP
+ * engine.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg may load it; nothing under raft_amd/ (the product) may call into it.
+ *
+ * The reference is Go (go.etcd.io/raft/v3 fork) and no Go toolchain exists in
+ * the build container, so the reference itself cannot be executed.  Parity is
+ * pinned instead by the reference's own golden vectors (quorum/testdata/ *.txt,
+ * 127 cases, re-encoded under tests/golden/) and test tables (TestCommit,
+ * TestLeaderAcknowledgeCommit, TestProgressUpdate), all of which this oracle
+ * must reproduce (tests/test_oracle_golden.py).
+ *
+ * Every function cites the reference file:line it follows (paths relative to
+ * the reference root).  The data shape follows the reference too: a config is
+ * a set of voter ids, an AckedIndexer / vote map is an id-keyed map (here: a
+ * small open-addressing hash map, standing in for Go's map).
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ORACLE_API __attribute__((visibility("default")))
+
+/* quorum/quorum.go:48-58 — VoteResult enum; 0 is not a valid value. */
+enum { VOTE_PENDING = 1, VOTE_LOST = 2, VOTE_WON = 3 };
+
+/* ------------------------------------------------------------------------ */
+/* A tiny id-keyed map: stands in for Go's map[uint64]T on the oracle side.  */
+/* ------------------------------------------------------------------------ */
+typedef struct {
+    uint64_t *keys;
+    uint64_t *vals;
+    uint8_t *used;
+    uint32_t cap; /* power of two */
+    uint32_t len;
+} idmap;
+
+static uint64_t mix64(uint64_t x) {
+    x ^= x >> 33;
+    x *= 0xff51afd7ed558ccdULL;
+    x ^= x >> 33;
+    x *= 0xc4ceb9fe1a85ec53ULL;
+    x ^= x >> 33;
+    return x;
+}
+
+static void idmap_init(idmap *m, uint32_t expect) {
+    uint32_t cap = 4;
+    while (cap < expect * 2 + 2) cap <<= 1;
+    m->cap = cap;
+    m->len = 0;
+    m->keys = (uint64_t *)calloc(cap, sizeof(uint64_t));
+    m->vals = (uint64_t *)calloc(cap, sizeof(uint64_t));
+    m->used = (uint8_t *)calloc(cap, 1);
+}
+
+static void idmap_free(idmap *m) {
+    free(m->keys);
+    free(m->vals);
+    free(m->used);
+}
+
+static void idmap_put(idmap *m, uint64_t k, uint64_t v) {
+    uint32_t i = (uint32_t)mix64(k) & (m->cap - 1);
+    while (m->used[i]) {
+        if (m->keys[i] == k) {
+            m->vals[i] = v;
+            return;
+        }
+        i = (i + 1) & (m->cap - 1);
+    }
+    m->used[i] = 1;
+    m->keys[i] = k;
+    m->vals[i] = v;
+    m->len++;
+}
+
+static int idmap_get(const idmap *m, uint64_t k, uint64_t *v) {
+    if (m->cap == 0) return 0;
+    uint32_t i = (uint32_t)mix64(k) & (m->cap - 1);
+    while (m->used[i]) {
+        if (m->keys[i] == k) {
+            *v = m->vals[i];
+            return 1;
+        }
+        i = (i + 1) & (m->cap - 1);
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------ */
+/* quorum package                                                            */
+/* ------------------------------------------------------------------------ */
+
+/* quorum/majority.go:115-122 — insertionSort, ascending. */
+static void insertion_sort(uint64_t *sl, int n) {
+    for (int i = 1; i < n; i++) {
+        for (int j = i; j > 0 && sl[j] < sl[j - 1]; j--) {
+            uint64_t t = sl[j];
+            sl[j] = sl[j - 1];
+            sl[j - 1] = t;
+        }
+    }
+}
+
+/*
+ * quorum/majority.go:126-172 — MajorityConfig.CommittedIndex.
+ * cfg: the n voter ids of the config.  l: the AckedIndexer
+ * (quorum/quorum.go:34-43), an id→index map; an absent id is "not found".
+ */
+static uint64_t majority_committed_index(const uint64_t *cfg, int n, const idmap *l) {
+    if (n == 0) return UINT64_MAX; /* majority.go:128-132 */
+    uint64_t stk[7];
+    uint64_t *srt = stk;
+    if (n > 7) srt = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)n); /* :141-147 */
+    memset(srt, 0, sizeof(uint64_t) * (size_t)n);
+    int i = n - 1; /* :154 fill from the right; unfound voters stay zero */
+    for (int k = 0; k < n; k++) {
+        uint64_t idx;
+        if (idmap_get(l, cfg[k], &idx)) {
+            srt[i] = idx;
+            i--;
+        }
+    }
+    insertion_sort(srt, n);       /* :165 */
+    int pos = n - (n / 2 + 1);    /* :170 */
+    uint64_t r = srt[pos];
+    if (srt != stk) free(srt);
+    return r;
+}
+
+/*
+ * quorum/quick_test.go:85-122 — alternativeMajorityCommittedIndex, the
+ * reference's own independent O(n^2) cross-check.
+ */
+static uint64_t alt_majority_committed_index(const uint64_t *cfg, int n, const idmap *l) {
+    if (n == 0) return UINT64_MAX;
+    uint64_t *have = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)n);
+    int m = 0;
+    for (int k = 0; k < n; k++) {
+        uint64_t idx;
+        if (idmap_get(l, cfg[k], &idx)) have[m++] = idx; /* idToIdx */
+    }
+    int q = n / 2 + 1;
+    uint64_t best = 0; /* maxQuorumIdx zero value, :114 */
+    for (int a = 0; a < m; a++) {      /* each distinct key idy of idxToVotes */
+        int votes = 0;
+        for (int b = 0; b < m; b++)    /* voters with idx >= idy, :103-110 */
+            if (!(have[a] > have[b])) votes++;
+        if (votes >= q && have[a] > best) best = have[a];
+    }
+    free(have);
+    return best;
+}
+
+/* quorum/joint.go:49-56 — JointConfig.CommittedIndex = min of the halves. */
+static uint64_t joint_committed_index(const uint64_t *c0, int n0, const uint64_t *c1, int n1,
+                                      const idmap *l) {
+    uint64_t idx0 = majority_committed_index(c0, n0, l);
+    uint64_t idx1 = majority_committed_index(c1, n1, l);
+    return idx0 < idx1 ? idx0 : idx1;
+}
+
+/*
+ * quorum/majority.go:178-207 — MajorityConfig.VoteResult.
+ * votes: id → 0 (false / rejected) or 1 (true / granted); absent = missing.
+ */
+static int majority_vote_result(const uint64_t *cfg, int n, const idmap *votes) {
+    if (n == 0) return VOTE_WON; /* :179-184 */
+    int voted = 0, missing = 0;
+    for (int k = 0; k < n; k++) {
+        uint64_t v;
+        if (!idmap_get(votes, cfg[k], &v)) {
+            missing++;
+            continue;
+        }
+        if (v) voted++;
+    }
+    int q = n / 2 + 1;
+    if (voted >= q) return VOTE_WON;
+    if (voted + missing >= q) return VOTE_PENDING;
+    return VOTE_LOST;
+}
+
+/* quorum/joint.go:61-75 — JointConfig.VoteResult. */
+static int joint_vote_result(const uint64_t *c0, int n0, const uint64_t *c1, int n1,
+                             const idmap *votes) {
+    int r1 = majority_vote_result(c0, n0, votes);
+    int r2 = majority_vote_result(c1, n1, votes);
+    if (r1 == r2) return r1;
+    if (r1 == VOTE_LOST || r2 == VOTE_LOST) return VOTE_LOST;
+    return VOTE_PENDING;
+}
+
+/* ------------------------------------------------------------------------ */
+/* Exported per-group entry points (id-level; used by the golden tests).     */
+/* A map is passed as parallel arrays (ids, vals, count).                    */
+/* ------------------------------------------------------------------------ */
+
+static void build_map(idmap *m, const uint64_t *ids, const uint64_t *vals, int n) {
+    idmap_init(m, (uint32_t)n);
+    for (int i = 0; i < n; i++) idmap_put(m, ids[i], vals[i]);
+}
+
+ORACLE_API uint64_t oracle_majority_committed_index(const uint64_t *cfg, int n,
+                                                    const uint64_t *l_ids, const uint64_t *l_idx,
+                                                    int l_n) {
+    idmap l;
+    build_map(&l, l_ids, l_idx, l_n);
+    uint64_t r = majority_committed_index(cfg, n, &l);
+    idmap_free(&l);
+    return r;
+}
+
+ORACLE_API uint64_t oracle_alt_majority_committed_index(const uint64_t *cfg, int n,
+                                                        const uint64_t *l_ids,
+                                                        const uint64_t *l_idx, int l_n) {
+    idmap l;
+    build_map(&l, l_ids, l_idx, l_n);
+    uint64_t r = alt_majority_committed_index(cfg, n, &l);
+    idmap_free(&l);
+    return r;
+}
+
+ORACLE_API uint64_t oracle_joint_committed_index(const uint64_t *c0, int n0, const uint64_t *c1,
+                                                 int n1, const uint64_t *l_ids,
+                                                 const uint64_t *l_idx, int l_n) {
+    idmap l;
+    build_map(&l, l_ids, l_idx, l_n);
+    uint64_t r = joint_committed_index(c0, n0, c1, n1, &l);
+    idmap_free(&l);
+    return r;
+}
+
+ORACLE_API int oracle_majority_vote_result(const uint64_t *cfg, int n, const uint64_t *v_ids,
+                                           const uint64_t *v_vals, int v_n) {
+    idmap v;
+    build_map(&v, v_ids, v_vals, v_n);
+    int r = majority_vote_result(cfg, n, &v);
+    idmap_free(&v);
+    return r;
+}
+
+ORACLE_API int oracle_joint_vote_result(const uint64_t *c0, int n0, const uint64_t *c1, int n1,
+                                        const uint64_t *v_ids, const uint64_t *v_vals, int v_n) {
+    idmap v;
+    build_map(&v, v_ids, v_vals, v_n);
+    int r = joint_vote_result(c0, n0, c1, n1, &v);
+    idmap_free(&v);
+    return r;
+}
+
+/*
+ * tracker/progress.go:168-177 — Progress.MaybeUpdate.  Returns `updated`.
+ * (MsgAppFlowPaused is host-side flow control and is not modelled.)
+ */
+ORACLE_API int oracle_maybe_update(uint64_t *match, uint64_t *next, uint64_t n) {
+    int updated = 0;
+    if (*match < n) {
+        *match = n;
+        updated = 1;
+    }
+    if (*next < n + 1) *next = n + 1;
+    return updated;
+}
+
+/*
+ * log.go:447-456 — raftLog.maybeCommit's guard, the consumer of the commit
+ * index (raft.go:755-758).  term_of_max is zeroTermOnOutOfBounds(term(maxIndex)).
+ * Returns the new committed value.
+ */
+ORACLE_API uint64_t oracle_log_maybe_commit(uint64_t committed, uint64_t max_index,
+                                            uint64_t term_of_max, uint64_t term) {
+    if (max_index > committed && term != 0 && term_of_max == term) return max_index;
+    return committed;
+}
+
+/* ------------------------------------------------------------------------ */
+/* Batched SoA views.  The engine's layout is [slot][group] planes plus two  */
+/* per-group slot bitmasks (incoming = Voters[0], outgoing = Voters[1]).     */
+/* The oracle turns every group back into the reference's shape (id sets +   */
+/* id-keyed maps, slot number = voter id) and runs the functions above.      */
+/* ------------------------------------------------------------------------ */
+
+static uint64_t load_mask(const void *masks, int mask_bytes, uint64_t g) {
+    switch (mask_bytes) {
+    case 1: return ((const uint8_t *)masks)[g];
+    case 2: return ((const uint16_t *)masks)[g];
+    case 4: return ((const uint32_t *)masks)[g];
+    default: return ((const uint64_t *)masks)[g];
+    }
+}
+
+static int mask_to_ids(uint64_t mask, int nslots, uint64_t *ids) {
+    int n = 0;
+    for (int s = 0; s < nslots; s++)
+        if ((mask >> s) & 1) ids[n++] = (uint64_t)s;
+    return n;
+}
+
+/*
+ * tracker/tracker.go:164-181 — ProgressTracker.Committed over G groups:
+ * Voters.CommittedIndex(matchAckIndexer(Progress)).  Every slot has a
+ * Progress row (voter or learner), so AckedIndex is always "found" and
+ * returns Match (tracker.go:169-175).  in_mask==NULL means "uniform": all
+ * groups have Voters[0] = slots [0,uniform_voters), Voters[1] empty.
+ */
+ORACLE_API void oracle_batch_committed(uint64_t G, int nslots, const uint64_t *match,
+                                       uint64_t stride, const void *in_mask,
+                                       const void *out_mask, int mask_bytes,
+                                       int uniform_voters, uint64_t *out, int threads) {
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+#pragma omp parallel
+#endif
+    {
+        uint64_t ids0[64], ids1[64], all[64], vals[64];
+        for (int s = 0; s < nslots; s++) all[s] = (uint64_t)s;
+#ifdef _OPENMP
+#pragma omp for schedule(static)
+#endif
+        for (int64_t g = 0; g < (int64_t)G; g++) {
+            uint64_t m0, m1;
+            if (in_mask) {
+                m0 = load_mask(in_mask, mask_bytes, (uint64_t)g);
+                m1 = out_mask ? load_mask(out_mask, mask_bytes, (uint64_t)g) : 0;
+            } else {
+                m0 = uniform_voters >= 64 ? ~0ULL : ((1ULL << uniform_voters) - 1);
+                m1 = 0;
+            }
+            int n0 = mask_to_ids(m0, nslots, ids0);
+            int n1 = mask_to_ids(m1, nslots, ids1);
+            for (int s = 0; s < nslots; s++) vals[s] = match[(uint64_t)s * stride + (uint64_t)g];
+            idmap l;
+            build_map(&l, all, vals, nslots);
+            out[g] = joint_committed_index(ids0, n0, ids1, n1, &l);
+            idmap_free(&l);
+        }
+    }
+}
+
+/*
+ * tracker/tracker.go:269-290 — TallyVotes over G groups.  votes plane cell:
+ * 0 = no vote recorded, 1 = rejected, 2 = granted (the encoding the
+ * reference's own harness uses, quorum/datadriven_test.go:55-58,94-100).
+ * learner_mask marks slots whose Progress.IsLearner is set (excluded from
+ * granted/rejected, tracker.go:275-277); all nslots slots have a Progress row.  result uses Voters only (:288).
+ * granted/rejected may be NULL.
+ */
+ORACLE_API void oracle_batch_tally_votes(uint64_t G, int nslots, const uint8_t *votes,
+                                         uint64_t stride, const void *in_mask,
+                                         const void *out_mask, const void *learner_mask,
+                                         int mask_bytes, int uniform_voters, uint8_t *result,
+                                         uint8_t *granted, uint8_t *rejected) {
+    uint64_t ids0[64], ids1[64], vid[64], vval[64];
+    for (uint64_t g = 0; g < G; g++) {
+        uint64_t m0, m1, ml;
+        if (in_mask) {
+            m0 = load_mask(in_mask, mask_bytes, g);
+            m1 = out_mask ? load_mask(out_mask, mask_bytes, g) : 0;
+            ml = learner_mask ? load_mask(learner_mask, mask_bytes, g) : 0;
+        } else {
+            m0 = uniform_voters >= 64 ? ~0ULL : ((1ULL << uniform_voters) - 1);
+            m1 = 0;
+            ml = nslots >= 64 ? ~m0 : (((1ULL << nslots) - 1) & ~m0);
+        }
+        int n0 = mask_to_ids(m0, nslots, ids0);
+        int n1 = mask_to_ids(m1, nslots, ids1);
+        int nv = 0, gr = 0, rj = 0;
+        for (int s = 0; s < nslots; s++) {
+            uint8_t c = votes[(uint64_t)s * stride + g];
+            if (c == 0) continue; /* no entry in Votes */
+            vid[nv] = (uint64_t)s;
+            vval[nv] = (c == 2);
+            nv++;
+            if (!((ml >> s) & 1)) { /* tracker.go:274-287 */
+                if (c == 2) gr++;
+                else rj++;
+            }
+        }
+        idmap v;
+        build_map(&v, vid, vval, nv);
+        result[g] = (uint8_t)joint_vote_result(ids0, n0, ids1, n1, &v);
+        idmap_free(&v);
+        if (granted) granted[g] = (uint8_t)gr;
+        if (rejected) rejected[g] = (uint8_t)rj;
+    }
+}
+
+/*
+ * tracker/tracker.go:217-227 — QuorumActive over G groups.  active bit s =
+ * Progress[s].RecentActive; learner slots are skipped (:220-222), every other
+ * Progress row gets an entry (true or false) in the votes map.
+ */
+ORACLE_API void oracle_batch_quorum_active(uint64_t G, int nslots, const void *active,
+                                           const void *in_mask, const void *out_mask,
+                                           const void *learner_mask, int mask_bytes,
+                                           int uniform_voters, uint8_t *out) {
+    uint64_t ids0[64], ids1[64], vid[64], vval[64];
+    for (uint64_t g = 0; g < G; g++) {
+        uint64_t m0, m1, ml;
+        if (in_mask) {
+            m0 = load_mask(in_mask, mask_bytes, g);
+            m1 = out_mask ? load_mask(out_mask, mask_bytes, g) : 0;
+            ml = learner_mask ? load_mask(learner_mask, mask_bytes, g) : 0;
+        } else {
+            m0 = uniform_voters >= 64 ? ~0ULL : ((1ULL << uniform_voters) - 1);
+            m1 = 0;
+            ml = nslots >= 64 ? ~m0 : (((1ULL << nslots) - 1) & ~m0);
+        }
+        uint64_t act = load_mask(active, mask_bytes, g);
+        int n0 = mask_to_ids(m0, nslots, ids0);
+        int n1 = mask_to_ids(m1, nslots, ids1);
+        int nv = 0;
+        for (int s = 0; s < nslots; s++) {
+            if ((ml >> s) & 1) continue;
+            vid[nv] = (uint64_t)s;
+            vval[nv] = (act >> s) & 1;
+            nv++;
+        }
+        idmap v;
+        build_map(&v, vid, vval, nv);
+        out[g] = joint_vote_result(ids0, n0, ids1, n1, &v) == VOTE_WON;
+        idmap_free(&v);
+    }
+}
+
+/*
+ * read_only.go:68-76 + raft.go:1552 — ReadIndex ack quorum over G groups.
+ * acks bit s set = acks[id]=true; the map never holds false (read_only.go:32-36),
+ * so an unset bit is a missing entry.  Output is the VoteResult enum.
+ */
+ORACLE_API void oracle_batch_ack_quorum(uint64_t G, int nslots, const void *acks,
+                                        const void *in_mask, const void *out_mask,
+                                        int mask_bytes, int uniform_voters, uint8_t *out) {
+    uint64_t ids0[64], ids1[64], vid[64], vval[64];
+    for (uint64_t g = 0; g < G; g++) {
+        uint64_t m0, m1;
+        if (in_mask) {
+            m0 = load_mask(in_mask, mask_bytes, g);
+            m1 = out_mask ? load_mask(out_mask, mask_bytes, g) : 0;
+        } else {
+            m0 = uniform_voters >= 64 ? ~0ULL : ((1ULL << uniform_voters) - 1);
+            m1 = 0;
+        }
+        uint64_t a = load_mask(acks, mask_bytes, g);
+        int n0 = mask_to_ids(m0, nslots, ids0);
+        int n1 = mask_to_ids(m1, nslots, ids1);
+        int nv = 0;
+        for (int s = 0; s < nslots; s++) {
+            if (!((a >> s) & 1)) continue;
+            vid[nv] = (uint64_t)s;
+            vval[nv] = 1;
+            nv++;
+        }
+        idmap v;
+        build_map(&v, vid, vval, nv);
+        out[g] = (uint8_t)joint_vote_result(ids0, n0, ids1, n1, &v);
+        idmap_free(&v);
+    }
+}
+
+/*
+ * raft.go:1333,1467-1477 → tracker/progress.go:168-177 — apply a stream of
+ * non-reject MsgAppResp acks in order: Match = max(Match, index) per
+ * (group, slot).  Records with group >= G or slot >= nslots are skipped and
+ * counted (the reference drops messages from unknown peers, raft.go:1327-1331).
+ * Returns the number skipped.
+ */
+typedef struct {
+    uint32_t group;
+    uint32_t slot;
+    uint64_t index;
+} oracle_ack;
+
+ORACLE_API uint64_t oracle_scatter_acks(uint64_t G, int nslots, uint64_t *match, uint64_t stride,
+                                        const oracle_ack *recs, uint64_t n) {
+    uint64_t skipped = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        if (recs[i].group >= G || recs[i].slot >= (uint32_t)nslots) {
+            skipped++;
+            continue;
+        }
+        uint64_t *cell = &match[(uint64_t)recs[i].slot * stride + recs[i].group];
+        uint64_t next = 0;
+        oracle_maybe_update(cell, &next, recs[i].index);
+    }
+    return skipped;
+}
+
+/* ------------------------------------------------------------------------ */
+/* CPU baseline (bench.py cpu_baseline leg, kind "port"): the reference's    */
+/* data shape — one id set + one id-keyed map per group, built up front —    */
+/* and a goroutine-per-core style parallel loop over groups calling          */
+/* CommittedIndex (quorum/bench_test.go:24-40 run across many groups).       */
+/* ------------------------------------------------------------------------ */
+typedef struct {
+    uint64_t G;
+    int V;
+    uint64_t *cfg; /* [G][V] voter ids */
+    idmap *l;      /* [G] */
+} oracle_bench;
+
+ORACLE_API void *oracle_bench_create(uint64_t G, int V, const uint64_t *match, uint64_t stride) {
+    oracle_bench *b = (oracle_bench *)calloc(1, sizeof(*b));
+    b->G = G;
+    b->V = V;
+    b->cfg = (uint64_t *)malloc(sizeof(uint64_t) * G * (size_t)V);
+    b->l = (idmap *)malloc(sizeof(idmap) * G);
+    for (uint64_t g = 0; g < G; g++) {
+        idmap_init(&b->l[g], (uint32_t)V);
+        for (int s = 0; s < V; s++) {
+            b->cfg[g * (uint64_t)V + (uint64_t)s] = (uint64_t)s + 1; /* ids 1..V, bench_test.go:30-31 */
+            idmap_put(&b->l[g], (uint64_t)s + 1, match[(uint64_t)s * stride + g]);
+        }
+    }
+    return b;
+}
+
+ORACLE_API int oracle_bench_run(void *h, uint64_t *out, int threads) {
+    oracle_bench *b = (oracle_bench *)h;
+    int used = 1;
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+#pragma omp parallel
+    {
+#pragma omp single
+        used = omp_get_num_threads();
+#pragma omp for schedule(static)
+        for (int64_t g = 0; g < (int64_t)b->G; g++)
+            out[g] = majority_committed_index(&b->cfg[(uint64_t)g * (uint64_t)b->V], b->V, &b->l[g]);
+    }
+#else
+    (void)threads;
+    for (uint64_t g = 0; g < b->G; g++)
+        out[g] = majority_committed_index(&b->cfg[g * (uint64_t)b->V], b->V, &b->l[g]);
+#endif
+    return used;
+}
+
+ORACLE_API void oracle_bench_destroy(void *h) {
+    oracle_bench *b = (oracle_bench *)h;
+    for (uint64_t g = 0; g < b->G; g++) idmap_free(&b->l[g]);
+    free(b->l);
+    free(b->cfg);
+    free(b);
+}
