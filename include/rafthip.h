@@ -1,0 +1,232 @@
+/*
+ * rafthip.h — C ABI of librafthip.so, the MI355X (gfx950) batched quorum engine.
+ *
+ * This is the drop-in boundary for ONE path of the reference (Elbehery/raft, a
+ * fork of go.etcd.io/raft/v3): evaluating, for many independent Raft groups at
+ * once, what quorum/ and tracker/ compute per group.  The reference has no FFI
+ * today; these entry points are what a cgo shim behind the new
+ * Go functions quorum.BatchCommittedIndex / quorum.BatchVoteResult binds to
+ * (INTEGRATION.md shows that shim).  Each declaration cites the reference
+ * code it replaces (paths relative to the reference root).
+ *
+ * Data model.  One engine per GPU holds G groups × S slots.  A slot is one
+ * Progress row of a group (tracker/tracker.go:117-126): a voter of the
+ * incoming config (Voters[0]), of the outgoing config (Voters[1]), or a
+ * learner.  The id→slot map is host-owned and changes only on conf change
+ * (confchange/confchange.go:51-145).  Device planes are laid out
+ * [slot][group] so that consecutive lanes read consecutive groups:
+ *
+ *   match    uint64 [S][G]   Progress.Match                (tracker/progress.go:31)
+ *   votes    uint8  [S][G]   0 no vote, 1 rejected, 2 granted
+ *                            (encoding of quorum/datadriven_test.go:55-58,94-100)
+ *   in/out/learner masks, active, acks:  one slot bitmask per group, bit s =
+ *                            slot s; width rafthip_mask_bytes() = 1/2/4/8 bytes
+ *                            for S <= 8/16/32/64
+ *   commit   uint64 [G]      last computed quorum commit index
+ *
+ * Conventions.  Every function returns 0 or a negative errno-style code and
+ * never throws or aborts (the reference's quorum/tracker functions return no
+ * errors; misuse panics — here misuse is an error return).  Pointers named
+ * `src`/`dst` may be host OR device memory (copies use hipMemcpyDefault).
+ * Compute calls are asynchronous on the engine's stream; read calls and
+ * rafthip_synchronize() wait for it.  Calls on one engine must be serialised
+ * by the caller (RawNode is "thread-unsafe" too, rawnode.go:31); different
+ * engines may be driven from different threads.  All arithmetic is uint64 /
+ * uint8 and bit-exact with the reference; there is no CPU fallback: without a
+ * usable GPU rafthip_create fails with RAFTHIP_ENODEV.
+ */
+#ifndef RAFTHIP_H
+#define RAFTHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RAFTHIP_ABI_VERSION 1u
+#define RAFTHIP_MAX_SLOTS 64u
+
+/* status codes */
+#define RAFTHIP_OK 0
+#define RAFTHIP_EINVAL (-22) /* bad argument / shape */
+#define RAFTHIP_ENOMEM (-12) /* device or host allocation failed */
+#define RAFTHIP_ENODEV (-19) /* no such GPU / not a usable HIP device */
+#define RAFTHIP_EIO (-5)     /* a HIP runtime call failed; see rafthip_last_error */
+#define RAFTHIP_ERANGE (-34) /* group range outside [0, num_groups) */
+
+/* quorum.VoteResult — quorum/quorum.go:48-58 (0 is not a valid result) */
+#define RAFTHIP_VOTE_PENDING 1
+#define RAFTHIP_VOTE_LOST 2
+#define RAFTHIP_VOTE_WON 3
+
+/* vote-plane cells — quorum/datadriven_test.go:55-58 */
+#define RAFTHIP_CELL_NONE 0
+#define RAFTHIP_CELL_REJECT 1
+#define RAFTHIP_CELL_GRANT 2
+
+typedef struct rafthip_engine rafthip_engine;
+
+typedef struct rafthip_config {
+    uint32_t struct_size; /* sizeof(rafthip_config), for ABI growth */
+    int32_t device;       /* HIP device ordinal */
+    uint64_t num_groups;  /* G >= 1 */
+    uint32_t num_slots;   /* S in [1, 64] */
+    uint32_t flags;       /* 0 */
+    void *stream;         /* hipStream_t to run on, or NULL: the engine makes its own */
+} rafthip_config;
+
+/* One non-reject MsgAppResp, already resolved to (group, slot):
+ * raftpb/raft.proto:71-108 Message{From→slot, Index}; handler raft.go:1333,1477. */
+typedef struct rafthip_ack {
+    uint32_t group;
+    uint32_t slot;
+    uint64_t index;
+} rafthip_ack;
+
+/* A group whose quorum commit index changed — what raft.maybeCommit
+ * (raft.go:755-758) hands to raftLog.maybeCommit (log.go:447-456). */
+typedef struct rafthip_commit_pair {
+    uint64_t group;
+    uint64_t commit;
+} rafthip_commit_pair;
+
+typedef struct rafthip_stats_t {
+    uint64_t commit_launches;   /* commit passes launched */
+    uint64_t groups_evaluated;  /* groups covered by all compute launches */
+    uint64_t acks_applied;      /* ack records submitted to rafthip_scatter_acks */
+    uint64_t acks_rejected;     /* of those, dropped: group/slot out of range */
+    uint64_t changed_reported;  /* pairs returned by rafthip_commit_changed */
+    uint64_t bytes_uploaded;
+    uint64_t bytes_downloaded;
+} rafthip_stats_t;
+
+/* ---- lifecycle ---------------------------------------------------------- */
+
+uint32_t rafthip_abi_version(void);
+/* Thread-local description of the last failure on this thread ("" if none). */
+const char *rafthip_last_error(void);
+int rafthip_device_count(int *count);
+
+/* Stands where tracker.MakeProgressTracker (tracker/tracker.go:129-145) stands
+ * per group: allocates zeroed planes; config is "empty" (both halves empty,
+ * which commits MaxUint64 / wins votes, majority.go:128-132,179-184). */
+int rafthip_create(const rafthip_config *cfg, rafthip_engine **out);
+int rafthip_destroy(rafthip_engine *e);
+int rafthip_synchronize(rafthip_engine *e);
+/* 1, 2, 4 or 8: bytes per slot bitmask for this engine's S. */
+int rafthip_mask_bytes(const rafthip_engine *e);
+int rafthip_stats(rafthip_engine *e, rafthip_stats_t *out);
+
+/* ---- configuration: tracker.Config (tracker/tracker.go:27-78) ----------- */
+
+/* Every group: Voters[0] = slots [0, voters), Voters[1] empty, the remaining
+ * slots learners.  The non-joint steady state (confchange.go:318-329); lets
+ * the kernels skip the mask planes. */
+int rafthip_set_uniform_config(rafthip_engine *e, uint32_t voters);
+
+/* Per-group configs for groups [first, first+count): bit s of in_mask[g] /
+ * out_mask[g] says slot s is in Voters[0] / Voters[1] (quorum/joint.go:19);
+ * learner_mask (may be NULL = none) marks Progress.IsLearner rows
+ * (tracker/progress.go:97).  Shapes per confchange/confchange.go:276-332. */
+int rafthip_upload_config(rafthip_engine *e, uint64_t first, uint64_t count, const void *in_mask,
+                          const void *out_mask, const void *learner_mask);
+
+/* ---- state -------------------------------------------------------------- */
+
+/* Progress.Match for groups [first, first+count), all S planes; plane s of the
+ * source starts at src + s*src_stride (elements). */
+int rafthip_upload_match(rafthip_engine *e, uint64_t first, uint64_t count, const uint64_t *src,
+                         uint64_t src_stride);
+/* Match = 0 for the range: what raft.reset does on every role change
+ * (raft.go:774-784). */
+int rafthip_reset_match(rafthip_engine *e, uint64_t first, uint64_t count);
+int rafthip_read_match(rafthip_engine *e, uint64_t first, uint64_t count, uint64_t *dst,
+                       uint64_t dst_stride);
+
+/* ProgressTracker.Votes (tracker/tracker.go:122,254-265) as vote-cell planes. */
+int rafthip_upload_votes(rafthip_engine *e, uint64_t first, uint64_t count, const uint8_t *src,
+                         uint64_t src_stride);
+/* ProgressTracker.ResetVotes — tracker/tracker.go:254-256. */
+int rafthip_reset_votes(rafthip_engine *e, uint64_t first, uint64_t count);
+
+/* Progress.RecentActive bits (tracker/progress.go:72; set at raft.go:1337,1528). */
+int rafthip_upload_active(rafthip_engine *e, uint64_t first, uint64_t count, const void *src);
+/* readIndexStatus.acks bits (read_only.go:29-37,68-76). */
+int rafthip_upload_acks(rafthip_engine *e, uint64_t first, uint64_t count, const void *src);
+/* Seed the commit plane (the value rafthip_commit_changed compares against). */
+int rafthip_upload_commit(rafthip_engine *e, uint64_t first, uint64_t count, const uint64_t *src);
+
+/* ---- compute ------------------------------------------------------------ */
+
+/* Progress.MaybeUpdate's Match part for a batch of acks — tracker/progress.go:168-177
+ * via raft.go:1477: Match = max(Match, index).  Max is commutative and
+ * idempotent, so the batch result equals applying the acks in any order.
+ * Records with group >= G or slot >= S are dropped and counted
+ * (stats.acks_rejected; the reference drops acks from unknown peers,
+ * raft.go:1327-1331). */
+int rafthip_scatter_acks(rafthip_engine *e, const rafthip_ack *recs, uint64_t n);
+
+/* ProgressTracker.Committed for every group — tracker/tracker.go:179-181 =
+ * JointConfig.CommittedIndex (quorum/joint.go:49-56) over
+ * MajorityConfig.CommittedIndex (quorum/majority.go:126-172) with
+ * matchAckIndexer (tracker/tracker.go:164-175).  Result → commit plane. */
+int rafthip_commit(rafthip_engine *e);
+
+/* Same pass, but also reports the groups whose commit index differs from the
+ * commit plane's previous content, sorted by group.  Waits for the GPU.
+ * *n_changed = number of pairs; up to max_pairs of them are copied to dst
+ * (host or device; may be NULL with max_pairs 0).  Consumer: raft.maybeCommit,
+ * raft.go:755-758. */
+int rafthip_commit_changed(rafthip_engine *e, rafthip_commit_pair *dst, uint64_t max_pairs,
+                           uint64_t *n_changed);
+int rafthip_read_commit(rafthip_engine *e, uint64_t first, uint64_t count, uint64_t *dst);
+
+/* ProgressTracker.TallyVotes for every group — tracker/tracker.go:269-290 →
+ * JointConfig.VoteResult (quorum/joint.go:61-75) over
+ * MajorityConfig.VoteResult (quorum/majority.go:178-207). */
+int rafthip_tally_votes(rafthip_engine *e);
+/* result: VoteResult per group; granted / rejected (either may be NULL):
+ * the informational counts of tracker.go:274-287. */
+int rafthip_read_vote_result(rafthip_engine *e, uint64_t first, uint64_t count, uint8_t *result,
+                             uint8_t *granted, uint8_t *rejected);
+
+/* ProgressTracker.QuorumActive for every group — tracker/tracker.go:217-227
+ * (CheckQuorum, raft.go:1231-1243).  Output 1 = active, 0 = not. */
+int rafthip_quorum_active(rafthip_engine *e);
+int rafthip_read_quorum_active(rafthip_engine *e, uint64_t first, uint64_t count, uint8_t *dst);
+
+/* ReadIndex ack quorum — Voters.VoteResult(acks) at raft.go:1552 with the
+ * yes-only map of read_only.go:68-76.  Output: VoteResult per group. */
+int rafthip_ack_quorum(rafthip_engine *e);
+int rafthip_read_ack_quorum(rafthip_engine *e, uint64_t first, uint64_t count, uint8_t *dst);
+
+/* ---- zero-copy access for hosts that fill planes on the GPU themselves --- */
+
+#define RAFTHIP_PLANE_MATCH 0  /* uint64 [S][stride] */
+#define RAFTHIP_PLANE_COMMIT 1 /* uint64 [stride]    */
+#define RAFTHIP_PLANE_VOTES 2  /* uint8  [S][stride] */
+/* Device address and plane stride (in elements) of an engine plane. */
+int rafthip_plane(rafthip_engine *e, int which, void **ptr, uint64_t *stride);
+
+/* ---- stateless one-shot forms (host or device pointers) ----------------- */
+
+/* What the new Go entry point quorum.BatchCommittedIndex binds to: for each of
+ * G groups, JointConfig{in,out}.CommittedIndex(l) (quorum/joint.go:49-56) with
+ * l.AckedIndex(slot) = (match[slot][g], true); pass 0 for a voter the indexer
+ * does not know (quorum/majority.go:149-161 leaves it 0).  Mask width as
+ * rafthip_mask_bytes for S; out_mask may be NULL (non-joint). */
+int rafthip_batch_committed_index(int device, uint64_t num_groups, uint32_t num_slots,
+                                  const uint64_t *match, const void *in_mask,
+                                  const void *out_mask, uint64_t *out);
+/* quorum.BatchVoteResult: JointConfig{in,out}.VoteResult(votes) per group
+ * (quorum/joint.go:61-75); votes are vote-cell planes [S][G]. */
+int rafthip_batch_vote_result(int device, uint64_t num_groups, uint32_t num_slots,
+                              const uint8_t *votes, const void *in_mask, const void *out_mask,
+                              uint8_t *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAFTHIP_H */

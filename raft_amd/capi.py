@@ -1,0 +1,296 @@
+"""ctypes binding of include/rafthip.h — one Python method per C entry point.
+
+Plumbing only: argument marshalling, error codes → exceptions.  All compute
+happens in librafthip.so on the GPU; a missing library raises RafthipError at
+load time (there is deliberately no fallback).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+ACK_DTYPE = np.dtype([("group", "<u4"), ("slot", "<u4"), ("index", "<u8")])
+PAIR_DTYPE = np.dtype([("group", "<u8"), ("commit", "<u8")])
+
+PLANE_MATCH, PLANE_COMMIT, PLANE_VOTES = 0, 1, 2
+VOTE_PENDING, VOTE_LOST, VOTE_WON = 1, 2, 3
+
+# every symbol include/rafthip.h declares (tests check the .so exports them all)
+SYMBOLS = [
+    "rafthip_abi_version", "rafthip_last_error", "rafthip_device_count", "rafthip_create",
+    "rafthip_destroy", "rafthip_synchronize", "rafthip_mask_bytes", "rafthip_stats",
+    "rafthip_set_uniform_config", "rafthip_upload_config", "rafthip_upload_match",
+    "rafthip_reset_match", "rafthip_read_match", "rafthip_upload_votes", "rafthip_reset_votes",
+    "rafthip_upload_active", "rafthip_upload_acks", "rafthip_upload_commit",
+    "rafthip_scatter_acks", "rafthip_commit", "rafthip_commit_changed", "rafthip_read_commit",
+    "rafthip_tally_votes", "rafthip_read_vote_result", "rafthip_quorum_active",
+    "rafthip_read_quorum_active", "rafthip_ack_quorum", "rafthip_read_ack_quorum",
+    "rafthip_plane", "rafthip_batch_committed_index", "rafthip_batch_vote_result",
+]
+
+
+class RafthipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("rafthip error %d: %s" % (code, msg))
+        self.code = code
+
+
+class _Config(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("num_groups", C.c_uint64),
+                ("num_slots", C.c_uint32), ("flags", C.c_uint32), ("stream", C.c_void_p)]
+
+
+class Stats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("commit_launches", "groups_evaluated", "acks_applied",
+                                           "acks_rejected", "changed_reported", "bytes_uploaded",
+                                           "bytes_downloaded")]
+
+
+def library_path():
+    return os.environ.get("RAFTHIP_LIBRARY", os.path.join(_HERE, "lib", "librafthip.so"))
+
+
+def load_library():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise RafthipError(-2, "%s not found: build it with `python -c 'import __graft_entry__ as g; "
+                           "g.build()'` (hipcc --offload-arch=gfx950); there is no CPU fallback" % path)
+    L = C.CDLL(path)
+    vp, u64, u32, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int
+    sig = {
+        "rafthip_abi_version": (u32, []),
+        "rafthip_last_error": (C.c_char_p, []),
+        "rafthip_device_count": (i32, [C.POINTER(C.c_int)]),
+        "rafthip_create": (i32, [C.POINTER(_Config), C.POINTER(vp)]),
+        "rafthip_destroy": (i32, [vp]),
+        "rafthip_synchronize": (i32, [vp]),
+        "rafthip_mask_bytes": (i32, [vp]),
+        "rafthip_stats": (i32, [vp, C.POINTER(Stats)]),
+        "rafthip_set_uniform_config": (i32, [vp, u32]),
+        "rafthip_upload_config": (i32, [vp, u64, u64, vp, vp, vp]),
+        "rafthip_upload_match": (i32, [vp, u64, u64, vp, u64]),
+        "rafthip_reset_match": (i32, [vp, u64, u64]),
+        "rafthip_read_match": (i32, [vp, u64, u64, vp, u64]),
+        "rafthip_upload_votes": (i32, [vp, u64, u64, vp, u64]),
+        "rafthip_reset_votes": (i32, [vp, u64, u64]),
+        "rafthip_upload_active": (i32, [vp, u64, u64, vp]),
+        "rafthip_upload_acks": (i32, [vp, u64, u64, vp]),
+        "rafthip_upload_commit": (i32, [vp, u64, u64, vp]),
+        "rafthip_scatter_acks": (i32, [vp, vp, u64]),
+        "rafthip_commit": (i32, [vp]),
+        "rafthip_commit_changed": (i32, [vp, vp, u64, C.POINTER(u64)]),
+        "rafthip_read_commit": (i32, [vp, u64, u64, vp]),
+        "rafthip_tally_votes": (i32, [vp]),
+        "rafthip_read_vote_result": (i32, [vp, u64, u64, vp, vp, vp]),
+        "rafthip_quorum_active": (i32, [vp]),
+        "rafthip_read_quorum_active": (i32, [vp, u64, u64, vp]),
+        "rafthip_ack_quorum": (i32, [vp]),
+        "rafthip_read_ack_quorum": (i32, [vp, u64, u64, vp]),
+        "rafthip_plane": (i32, [vp, i32, C.POINTER(vp), C.POINTER(u64)]),
+        "rafthip_batch_committed_index": (i32, [i32, u64, u32, vp, vp, vp, vp]),
+        "rafthip_batch_vote_result": (i32, [i32, u64, u32, vp, vp, vp, vp]),
+    }
+    assert sorted(sig) == sorted(SYMBOLS)
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype, fn.argtypes = res, args
+    _LIB = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise RafthipError(rc, load_library().rafthip_last_error().decode("utf-8", "replace"))
+
+
+def mask_dtype(nslots):
+    return np.dtype(np.uint8 if nslots <= 8 else np.uint16 if nslots <= 16
+                    else np.uint32 if nslots <= 32 else np.uint64)
+
+
+def _ptr(a):
+    """Host numpy array, torch tensor (host or device), raw int address, or None → void*."""
+    if a is None:
+        return None
+    if isinstance(a, int):
+        return C.c_void_p(a)
+    if isinstance(a, np.ndarray):
+        if not a.flags["C_CONTIGUOUS"]:
+            raise ValueError("array must be C-contiguous")
+        return C.c_void_p(a.ctypes.data)
+    if hasattr(a, "data_ptr"):
+        if not a.is_contiguous():
+            raise ValueError("tensor must be contiguous")
+        return C.c_void_p(a.data_ptr())
+    raise TypeError("unsupported buffer type %r" % type(a))
+
+
+class Engine:
+    """One engine per GPU: G groups × S slots of device-resident state."""
+
+    def __init__(self, num_groups, num_slots, device=0, stream=None):
+        self._h = None
+        L = load_library()
+        cfg = _Config(C.sizeof(_Config), device, num_groups, num_slots, 0, stream)
+        h = C.c_void_p()
+        _check(L.rafthip_create(C.byref(cfg), C.byref(h)))
+        self._L, self._h = L, h
+        self.G, self.S, self.device = num_groups, num_slots, device
+        self.mask_dtype = mask_dtype(num_slots)
+        assert L.rafthip_mask_bytes(h) == self.mask_dtype.itemsize
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.rafthip_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _range(self, first, count):
+        return first, (self.G - first if count is None else count)
+
+    # configuration
+    def set_uniform_config(self, voters):
+        _check(self._L.rafthip_set_uniform_config(self._h, voters))
+
+    def upload_config(self, in_mask, out_mask, learner_mask=None, first=0, count=None):
+        first, count = self._range(first, count)
+        _check(self._L.rafthip_upload_config(self._h, first, count, _ptr(in_mask), _ptr(out_mask),
+                                             _ptr(learner_mask)))
+
+    # state
+    def upload_match(self, match, first=0, count=None, src_stride=None):
+        first, count = self._range(first, count)
+        if src_stride is None:
+            src_stride = match.shape[1] if hasattr(match, "shape") else count
+        _check(self._L.rafthip_upload_match(self._h, first, count, _ptr(match), src_stride))
+
+    def reset_match(self, first=0, count=None):
+        first, count = self._range(first, count)
+        _check(self._L.rafthip_reset_match(self._h, first, count))
+
+    def read_match(self, first=0, count=None):
+        first, count = self._range(first, count)
+        out = np.empty((self.S, count), dtype=np.uint64)
+        _check(self._L.rafthip_read_match(self._h, first, count, _ptr(out), count))
+        return out
+
+    def upload_votes(self, votes, first=0, count=None, src_stride=None):
+        first, count = self._range(first, count)
+        if src_stride is None:
+            src_stride = votes.shape[1] if hasattr(votes, "shape") else count
+        _check(self._L.rafthip_upload_votes(self._h, first, count, _ptr(votes), src_stride))
+
+    def reset_votes(self, first=0, count=None):
+        first, count = self._range(first, count)
+        _check(self._L.rafthip_reset_votes(self._h, first, count))
+
+    def upload_active(self, bits, first=0, count=None):
+        first, count = self._range(first, count)
+        _check(self._L.rafthip_upload_active(self._h, first, count, _ptr(bits)))
+
+    def upload_acks(self, bits, first=0, count=None):
+        first, count = self._range(first, count)
+        _check(self._L.rafthip_upload_acks(self._h, first, count, _ptr(bits)))
+
+    def upload_commit(self, commit, first=0, count=None):
+        first, count = self._range(first, count)
+        _check(self._L.rafthip_upload_commit(self._h, first, count, _ptr(commit)))
+
+    # compute
+    def scatter_acks(self, recs, n=None):
+        if n is None:
+            n = len(recs)
+        _check(self._L.rafthip_scatter_acks(self._h, _ptr(recs), n))
+
+    def commit(self):
+        _check(self._L.rafthip_commit(self._h))
+
+    def commit_changed(self, max_pairs=None):
+        """Returns (pairs[PAIR_DTYPE], n_changed)."""
+        if max_pairs is None:
+            max_pairs = self.G
+        out = np.empty(max_pairs, dtype=PAIR_DTYPE)
+        n = C.c_uint64()
+        _check(self._L.rafthip_commit_changed(self._h, _ptr(out) if max_pairs else None, max_pairs,
+                                              C.byref(n)))
+        return out[:min(n.value, max_pairs)], n.value
+
+    def read_commit(self, first=0, count=None):
+        first, count = self._range(first, count)
+        out = np.empty(count, dtype=np.uint64)
+        _check(self._L.rafthip_read_commit(self._h, first, count, _ptr(out)))
+        return out
+
+    def tally_votes(self):
+        _check(self._L.rafthip_tally_votes(self._h))
+
+    def read_vote_result(self, first=0, count=None, counts=True):
+        first, count = self._range(first, count)
+        res = np.empty(count, dtype=np.uint8)
+        gr = np.empty(count, dtype=np.uint8) if counts else None
+        rj = np.empty(count, dtype=np.uint8) if counts else None
+        _check(self._L.rafthip_read_vote_result(self._h, first, count, _ptr(res), _ptr(gr), _ptr(rj)))
+        return (res, gr, rj) if counts else res
+
+    def quorum_active(self):
+        _check(self._L.rafthip_quorum_active(self._h))
+
+    def read_quorum_active(self, first=0, count=None):
+        first, count = self._range(first, count)
+        out = np.empty(count, dtype=np.uint8)
+        _check(self._L.rafthip_read_quorum_active(self._h, first, count, _ptr(out)))
+        return out
+
+    def ack_quorum(self):
+        _check(self._L.rafthip_ack_quorum(self._h))
+
+    def read_ack_quorum(self, first=0, count=None):
+        first, count = self._range(first, count)
+        out = np.empty(count, dtype=np.uint8)
+        _check(self._L.rafthip_read_ack_quorum(self._h, first, count, _ptr(out)))
+        return out
+
+    def synchronize(self):
+        _check(self._L.rafthip_synchronize(self._h))
+
+    def stats(self):
+        s = Stats()
+        _check(self._L.rafthip_stats(self._h, C.byref(s)))
+        return {n: getattr(s, n) for n, _ in Stats._fields_}
+
+    def plane(self, which):
+        """(device address, stride in elements) of an engine plane."""
+        p, st = C.c_void_p(), C.c_uint64()
+        _check(self._L.rafthip_plane(self._h, which, C.byref(p), C.byref(st)))
+        return p.value, st.value
+
+
+def batch_committed_index(match, in_mask, out_mask=None, device=0):
+    """quorum.BatchCommittedIndex: match u64 [S][G], slot masks [G] → u64 [G]."""
+    S, G = match.shape
+    out = np.empty(G, dtype=np.uint64)
+    _check(load_library().rafthip_batch_committed_index(device, G, S, _ptr(match), _ptr(in_mask),
+                                                        _ptr(out_mask), _ptr(out)))
+    return out
+
+
+def batch_vote_result(votes, in_mask, out_mask=None, device=0):
+    """quorum.BatchVoteResult: vote cells u8 [S][G], slot masks [G] → VoteResult u8 [G]."""
+    S, G = votes.shape
+    out = np.empty(G, dtype=np.uint8)
+    _check(load_library().rafthip_batch_vote_result(device, G, S, _ptr(votes), _ptr(in_mask),
+                                                    _ptr(out_mask), _ptr(out)))
+    return out

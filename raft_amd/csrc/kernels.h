@@ -1,0 +1,625 @@
+// kernels.h — gfx950 device code of the batched quorum engine.
+//
+// Everything here is integer order-statistic / popcount work bound by HBM
+// bandwidth (no MFMA: there is no contraction on this path).  Layout rule:
+// planes are [slot][group], so lane i of a wavefront touches group i and every
+// global access is a contiguous 16-byte-per-lane stream.
+//
+//   K1  k_commit_uniform   non-joint, same voter slots in every group, V <= 8
+//   K2  k_commit_masked    per-group incoming/outgoing slot masks, S <= 8
+//   K4  k_commit_wide      9..64 slots: LDS-staged transpose + wave bitonic sort
+//   K3  k_tally_*          VoteResult / QuorumActive / ReadIndex-ack tallies
+//   K5  k_scatter_acks     MsgAppResp stream -> atomicMax on Match
+//       k_scan_counts / k_pack_pairs   ordered compaction of changed commits
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <utility>
+
+#include "sortnet.h"
+
+namespace rafthip {
+
+using u64 = unsigned long long;
+using u32 = unsigned int;
+
+constexpr int kBlock = 256;        // threads per workgroup: 4 wavefronts of 64
+constexpr u64 kPlaneAlign = 4096;  // plane stride granule (elements)
+constexpr u64 kU64Max = ~0ull;
+
+struct Pair {  // = rafthip_commit_pair
+    u64 group;
+    u64 commit;
+};
+struct Ack {  // = rafthip_ack
+    u32 group;
+    u32 slot;
+    u64 index;
+};
+
+template <typename T, int N>
+struct alignas(sizeof(T) * N) Vec {
+    T v[N];
+};
+
+template <typename T, int N>
+__device__ __forceinline__ Vec<T, N> load_vec(const T* p) {
+    return *reinterpret_cast<const Vec<T, N>*>(p);
+}
+template <typename T, int N>
+__device__ __forceinline__ void store_vec(T* p, const Vec<T, N>& x) {
+    *reinterpret_cast<Vec<T, N>*>(p) = x;
+}
+
+// ---------------------------------------------------------------------------
+// Register sorting network (ascending).  Replaces insertionSort,
+// quorum/majority.go:115-122.
+// ---------------------------------------------------------------------------
+template <int A, int B, int N>
+__device__ __forceinline__ void cex(u64 (&v)[N]) {
+    const u64 x = v[A], y = v[B];
+    const bool lt = x < y;  // unsigned: Match values may be >= 2^63
+    v[A] = lt ? x : y;
+    v[B] = lt ? y : x;
+}
+template <int N, int... K>
+__device__ __forceinline__ void sort_impl(u64 (&v)[N], std::integer_sequence<int, K...>) {
+    (cex<SortNet<N>::ce[K].a, SortNet<N>::ce[K].b, N>(v), ...);
+}
+template <int N>
+__device__ __forceinline__ void sort_asc(u64 (&v)[N]) {
+    if constexpr (SortNet<N>::n > 0) sort_impl<N>(v, std::make_integer_sequence<int, SortNet<N>::n>{});
+}
+
+// MajorityConfig.CommittedIndex for a config of exactly V voters held in v[]:
+// sort, take srt[n-(n/2+1)] — quorum/majority.go:165-171.
+template <int V>
+__device__ __forceinline__ u64 committed_fixed(u64 (&v)[V]) {
+    sort_asc<V>(v);
+    return v[V - (V / 2 + 1)];
+}
+
+// MajorityConfig.CommittedIndex for the voters selected by slot mask m out of
+// S slots.  Non-members are replaced by 0, the smallest key, so after the
+// sort the n members occupy the top n places value-wise and the q-th largest
+// member sits at ascending position S-q.  n == 0 -> MaxUint64
+// (quorum/majority.go:128-132).
+template <int S>
+__device__ __forceinline__ u64 committed_masked(const u64 (&v)[S], u32 m) {
+    m &= (1u << S) - 1u;
+    u64 a[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) a[s] = ((m >> s) & 1u) ? v[s] : 0ull;
+    sort_asc<S>(a);
+    const int n = __popc(m);
+    const int pos = S - (n / 2 + 1);
+    constexpr int kLo = S - (S / 2 + 1);  // smallest position any n can select
+    u64 r = a[kLo];
+#pragma unroll
+    for (int i = kLo + 1; i < S; ++i) r = (pos == i) ? a[i] : r;
+    return m == 0 ? kU64Max : r;
+}
+
+// ---------------------------------------------------------------------------
+// Ordered in-block compaction of changed (group, commit) pairs.  Block b owns
+// stage[b*BG .. (b+1)*BG) and counts[b]; no atomics, so the packed output is
+// sorted by group and reproducible.
+// ---------------------------------------------------------------------------
+template <int GPT>
+__device__ __forceinline__ void emit_changed(const bool (&ch)[GPT], const u64 (&grp)[GPT],
+                                             const u64 (&val)[GPT], Pair* __restrict__ stage,
+                                             u32* __restrict__ counts) {
+    __shared__ u32 wave_tot[kBlock / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const u64 lt = (1ull << lane) - 1ull;
+    u32 before = 0, total = 0;
+#pragma unroll
+    for (int j = 0; j < GPT; ++j) {
+        const u64 b = __ballot(ch[j]);
+        before += __popcll(b & lt);
+        total += __popcll(b);
+    }
+    if (lane == 0) wave_tot[wave] = total;
+    __syncthreads();
+    u32 base = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; ++w) {
+        const u32 t = wave_tot[w];
+        base += (w < wave) ? t : 0u;
+        all += t;
+    }
+    Pair* out = stage + (u64)blockIdx.x * (u64)(kBlock * GPT);
+    u32 pos = base + before;
+#pragma unroll
+    for (int j = 0; j < GPT; ++j) {
+        if (ch[j]) {
+            out[pos] = Pair{grp[j], val[j]};
+            ++pos;
+        }
+    }
+    if (threadIdx.x == 0) counts[blockIdx.x] = all;
+}
+
+// ---------------------------------------------------------------------------
+// K1 — ProgressTracker.Committed, uniform non-joint config of V voters.
+// One lane evaluates GPT consecutive groups; per plane it issues 16-byte loads.
+// ---------------------------------------------------------------------------
+template <int V, int GPT, bool CHANGED>
+__global__ __launch_bounds__(kBlock) void k_commit_uniform(const u64* __restrict__ match, u64 stride,
+                                                           u64 G, u64* __restrict__ commit,
+                                                           Pair* __restrict__ stage,
+                                                           u32* __restrict__ counts) {
+    const u64 g0 = ((u64)blockIdx.x * kBlock + threadIdx.x) * GPT;
+    Vec<u64, GPT> in[V];
+#pragma unroll
+    for (int s = 0; s < V; ++s) in[s] = load_vec<u64, GPT>(match + (u64)s * stride + g0);
+    Vec<u64, GPT> res;
+#pragma unroll
+    for (int j = 0; j < GPT; ++j) {
+        u64 a[V];
+#pragma unroll
+        for (int s = 0; s < V; ++s) a[s] = in[s].v[j];
+        res.v[j] = committed_fixed<V>(a);
+    }
+    if constexpr (CHANGED) {
+        const Vec<u64, GPT> old = load_vec<u64, GPT>(commit + g0);
+        bool ch[GPT];
+        u64 grp[GPT], val[GPT];
+#pragma unroll
+        for (int j = 0; j < GPT; ++j) {
+            grp[j] = g0 + j;
+            val[j] = res.v[j];
+            ch[j] = (grp[j] < G) && (old.v[j] != res.v[j]);
+        }
+        store_vec<u64, GPT>(commit + g0, res);
+        emit_changed<GPT>(ch, grp, val, stage, counts);
+    } else {
+        store_vec<u64, GPT>(commit + g0, res);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K2 — ProgressTracker.Committed with per-group joint configs, S <= 8 slots:
+// min(CommittedIndex(incoming), CommittedIndex(outgoing)), quorum/joint.go:49-56.
+// ---------------------------------------------------------------------------
+template <int S, int GPT, bool CHANGED>
+__global__ __launch_bounds__(kBlock) void k_commit_masked(const u64* __restrict__ match, u64 stride,
+                                                          u64 G, const uint8_t* __restrict__ in_mask,
+                                                          const uint8_t* __restrict__ out_mask,
+                                                          u64* __restrict__ commit,
+                                                          Pair* __restrict__ stage,
+                                                          u32* __restrict__ counts) {
+    const u64 g0 = ((u64)blockIdx.x * kBlock + threadIdx.x) * GPT;
+    Vec<u64, GPT> in[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) in[s] = load_vec<u64, GPT>(match + (u64)s * stride + g0);
+    const Vec<uint8_t, GPT> m0 = load_vec<uint8_t, GPT>(in_mask + g0);
+    const Vec<uint8_t, GPT> m1 = load_vec<uint8_t, GPT>(out_mask + g0);
+    bool any_out = false;
+#pragma unroll
+    for (int j = 0; j < GPT; ++j) any_out |= (m1.v[j] != 0);
+    // Joint configs are transient (confchange.go:51-126); when no lane of the
+    // wavefront holds one, the outgoing half is skipped for the whole wave.
+    const bool wave_joint = __any(any_out);
+    Vec<u64, GPT> res;
+#pragma unroll
+    for (int j = 0; j < GPT; ++j) {
+        u64 a[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) a[s] = in[s].v[j];
+        u64 r = committed_masked<S>(a, m0.v[j]);
+        if (wave_joint) {
+            const u64 r1 = committed_masked<S>(a, m1.v[j]);
+            r = r1 < r ? r1 : r;
+        }
+        res.v[j] = r;
+    }
+    if constexpr (CHANGED) {
+        const Vec<u64, GPT> old = load_vec<u64, GPT>(commit + g0);
+        bool ch[GPT];
+        u64 grp[GPT], val[GPT];
+#pragma unroll
+        for (int j = 0; j < GPT; ++j) {
+            grp[j] = g0 + j;
+            val[j] = res.v[j];
+            ch[j] = (grp[j] < G) && (old.v[j] != res.v[j]);
+        }
+        store_vec<u64, GPT>(commit + g0, res);
+        emit_changed<GPT>(ch, grp, val, stage, counts);
+    } else {
+        store_vec<u64, GPT>(commit + g0, res);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K4 — wide voter sets (9..64 slots).  A wavefront stages a 64-group tile of
+// every plane in LDS (coalesced reads), then turns the tile: lane = slot.
+// W = 16/32/64 lanes form one group's sort segment, so 64/W groups are sorted
+// per step by a cross-lane bitonic network (DPP for distance 1-2, ds_swizzle
+// for 4-16, a permute for 32).
+// ---------------------------------------------------------------------------
+template <int J>
+__device__ __forceinline__ u32 xor_lane32(u32 x) {
+    if constexpr (J == 1) {
+        return (u32)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
+    } else if constexpr (J == 2) {
+        return (u32)__builtin_amdgcn_mov_dpp((int)x, 0x4E, 0xF, 0xF, true);  // quad_perm [2,3,0,1]
+    } else if constexpr (J <= 16) {
+        return (u32)__builtin_amdgcn_ds_swizzle((int)x, (J << 10) | 0x1F);  // bit mode: lane ^ J
+    } else {
+        return (u32)__shfl_xor((int)x, J, 64);
+    }
+}
+template <int J>
+__device__ __forceinline__ u64 xor_lane64(u64 x) {
+    const u32 lo = xor_lane32<J>((u32)x), hi = xor_lane32<J>((u32)(x >> 32));
+    return ((u64)hi << 32) | lo;
+}
+
+template <int K, int J>
+__device__ __forceinline__ u64 bitonic_step(u64 key, int sl) {
+    const u64 other = xor_lane64<J>(key);
+    const bool asc = (sl & K) == 0;
+    const bool lower = (sl & J) == 0;
+    const bool keep_min = (lower == asc);
+    const bool lt = key < other;
+    return (keep_min == lt) ? key : other;
+}
+template <int K, int J>
+__device__ __forceinline__ u64 bitonic_merge(u64 key, int sl) {
+    key = bitonic_step<K, J>(key, sl);
+    if constexpr (J > 1) key = bitonic_merge<K, J / 2>(key, sl);
+    return key;
+}
+template <int W, int K>
+__device__ __forceinline__ u64 bitonic_sort(u64 key, int sl) {
+    key = bitonic_merge<K, K / 2>(key, sl);
+    if constexpr (K < W) key = bitonic_sort<W, K * 2>(key, sl);
+    return key;
+}
+
+// q-th largest of the member keys of one W-lane segment (ascending sort,
+// position W-q); n == 0 -> MaxUint64.
+template <int W>
+__device__ __forceinline__ u64 wide_half(u64 val, u64 mask, int sl, int seg_base) {
+    const u64 key = ((mask >> sl) & 1ull) ? val : 0ull;
+    const u64 sorted = bitonic_sort<W, 2>(key, sl);
+    const int n = __popcll(mask);
+    const int src = seg_base + (W - (n / 2 + 1));
+    const u32 lo = (u32)__shfl((int)(u32)sorted, src, 64);
+    const u32 hi = (u32)__shfl((int)(u32)(sorted >> 32), src, 64);
+    const u64 r = ((u64)hi << 32) | lo;
+    return n == 0 ? kU64Max : r;
+}
+
+constexpr int kTileStride = 65;  // u64 per LDS tile row: 64 groups + 1 pad (bank spread)
+
+template <int W, typename MaskT, bool CHANGED>
+__global__ __launch_bounds__(kBlock) void k_commit_wide(const u64* __restrict__ match, u64 stride,
+                                                        u64 G, int S, const MaskT* __restrict__ in_mask,
+                                                        const MaskT* __restrict__ out_mask,
+                                                        int uniform_voters, u64* __restrict__ commit,
+                                                        Pair* __restrict__ stage,
+                                                        u32* __restrict__ counts) {
+    extern __shared__ u64 lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    u64* tile = lds + (size_t)wave * (size_t)S * kTileStride;
+    const u64 g = (u64)blockIdx.x * kBlock + threadIdx.x;  // < stride (stride is a multiple of 4096)
+    for (int s = 0; s < S; ++s) tile[s * kTileStride + lane] = match[(u64)s * stride + g];
+    u64 m0, m1;
+    if (in_mask) {
+        m0 = (u64)in_mask[g];
+        m1 = (u64)out_mask[g];
+    } else {
+        m0 = uniform_voters >= 64 ? kU64Max : ((1ull << uniform_voters) - 1ull);
+        m1 = 0;
+    }
+    if (S < 64) {
+        const u64 valid = (1ull << S) - 1ull;
+        m0 &= valid;
+        m1 &= valid;
+    }
+    __syncthreads();
+    constexpr int GPI = 64 / W;  // groups sorted per step
+    const int sub = lane / W, sl = lane % W, seg_base = sub * W;
+    const bool wave_joint = __any(m1 != 0);
+    u64 res = 0;
+#pragma unroll 1
+    for (int it = 0; it < 64 / GPI; ++it) {
+        const int gl = it * GPI + sub;  // tile-local group this segment sorts
+        const u64 val = (sl < S) ? tile[sl * kTileStride + gl] : 0ull;
+        const u64 mm0 = ((u64)(u32)__shfl((int)(u32)(m0 >> 32), gl, 64) << 32) |
+                        (u64)(u32)__shfl((int)(u32)m0, gl, 64);
+        u64 r = wide_half<W>(val, mm0, sl, seg_base);
+        if (wave_joint) {
+            const u64 mm1 = ((u64)(u32)__shfl((int)(u32)(m1 >> 32), gl, 64) << 32) |
+                            (u64)(u32)__shfl((int)(u32)m1, gl, 64);
+            const u64 r1 = wide_half<W>(val, mm1, sl, seg_base);
+            r = r1 < r ? r1 : r;
+        }
+        // lane L owns group L of the tile: sorted in step L/GPI by segment L%GPI
+        const int owner_seg = (lane % GPI) * W;
+        const u64 rr = ((u64)(u32)__shfl((int)(u32)(r >> 32), owner_seg, 64) << 32) |
+                       (u64)(u32)__shfl((int)(u32)r, owner_seg, 64);
+        if (lane / GPI == it) res = rr;
+    }
+    if constexpr (CHANGED) {
+        const u64 old = commit[g];
+        bool ch[1] = {(g < G) && (old != res)};
+        u64 grp[1] = {g}, val[1] = {res};
+        commit[g] = res;
+        emit_changed<1>(ch, grp, val, stage, counts);
+    } else {
+        commit[g] = res;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Changed-pair packing: exclusive scan of per-block counts, then copy every
+// block's ordered run to its offset.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_scan_counts(const u32* __restrict__ counts, u32 nblocks,
+                                                      u64* __restrict__ offsets) {
+    __shared__ u64 part[1024];
+    const u32 t = threadIdx.x;
+    const u32 per = (nblocks + 1023u) / 1024u;
+    const u32 lo = t * per, hi = (lo + per < nblocks) ? lo + per : nblocks;
+    u64 sum = 0;
+    for (u32 i = lo; i < hi; ++i) sum += counts[i];
+    part[t] = sum;
+    __syncthreads();
+    for (u32 d = 1; d < 1024; d <<= 1) {  // Hillis-Steele inclusive scan
+        const u64 add = (t >= d) ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += add;
+        __syncthreads();
+    }
+    u64 run = part[t] - sum;
+    for (u32 i = lo; i < hi; ++i) {
+        offsets[i] = run;
+        run += counts[i];
+    }
+    if (t == 1023) offsets[nblocks] = part[1023];
+}
+
+__global__ __launch_bounds__(kBlock) void k_pack_pairs(const Pair* __restrict__ stage,
+                                                       const u32* __restrict__ counts,
+                                                       const u64* __restrict__ offsets, u32 block_groups,
+                                                       Pair* __restrict__ packed) {
+    const u32 n = counts[blockIdx.x];
+    const Pair* src = stage + (u64)blockIdx.x * block_groups;
+    Pair* dst = packed + offsets[blockIdx.x];
+    for (u32 i = threadIdx.x; i < n; i += kBlock) dst[i] = src[i];
+}
+
+// ---------------------------------------------------------------------------
+// K5 — Progress.MaybeUpdate (Match part) for a stream of acks:
+// Match = max(Match, index), tracker/progress.go:170-173.  64-bit atomic max is
+// order-independent, so duplicates and stale acks inside a batch are exact.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_scatter_acks(u64* __restrict__ match, u64 stride, u64 G,
+                                                         u32 S, const Ack* __restrict__ recs, u64 n,
+                                                         u64* __restrict__ rejected) {
+    const u64 i = (u64)blockIdx.x * kBlock + threadIdx.x;
+    bool bad = false;
+    if (i < n) {
+        const Vec<u64, 2> raw = load_vec<u64, 2>(reinterpret_cast<const u64*>(recs + i));
+        const u32 group = (u32)raw.v[0], slot = (u32)(raw.v[0] >> 32);
+        const u64 index = raw.v[1];
+        if ((u64)group < G && slot < S) {
+            atomicMax(match + (u64)slot * stride + group, index);
+        } else {
+            bad = true;
+        }
+    }
+    const u64 b = __ballot(bad);
+    if (b != 0 && (threadIdx.x & 63) == 0) atomicAdd(rejected, (u64)__popcll(b));
+}
+
+// ---------------------------------------------------------------------------
+// K3 — tallies, S <= 8 (one mask byte per group).  A lane handles 16 groups:
+// one 16-byte load per plane, arithmetic done four groups at a time on the
+// bytes of a dword (counts never exceed 8, so bytes cannot carry).
+// ---------------------------------------------------------------------------
+constexpr u32 k01 = 0x01010101u, k80 = 0x80808080u;
+
+__device__ __forceinline__ u32 swar_popc8(u32 x) {  // per-byte popcount
+    x = x - ((x >> 1) & 0x55555555u);
+    x = (x & 0x33333333u) + ((x >> 2) & 0x33333333u);
+    return (x + (x >> 4)) & 0x0F0F0F0Fu;
+}
+// bit 7 of each byte set iff a >= b (bytes < 128)
+__device__ __forceinline__ u32 swar_ge(u32 a, u32 b) { return ((a | k80) - b) & k80; }
+// bit 7 of each byte set iff the byte is zero (bytes < 128)
+__device__ __forceinline__ u32 swar_is0(u32 a) { return ~((a | k80) - k01) & k80; }
+
+// MajorityConfig.VoteResult on 4 groups: n voters, yes and no counts per byte.
+// Returns (won, lost) as bit-7 flags.  quorum/majority.go:178-207.
+__device__ __forceinline__ void swar_vote_half(u32 n, u32 yes, u32 no, u32& won, u32& lost) {
+    const u32 q = ((n >> 1) & 0x7F7F7F7Fu) + k01;  // n/2+1
+    const u32 empty = swar_is0(n);                 // n == 0 -> VoteWon (:179-184)
+    won = swar_ge(yes, q) | empty;
+    const u32 pend_or_won = swar_ge(n - no, q) | empty;  // yes + missing = n - no
+    lost = ~pend_or_won & k80;
+}
+// JointConfig.VoteResult, quorum/joint.go:61-75: Won iff both won; Lost if
+// either lost; else Pending.  Encoded 1 + 2*won + lost per byte.
+__device__ __forceinline__ u32 swar_joint(u32 won0, u32 lost0, u32 won1, u32 lost1) {
+    const u32 w = ((won0 & won1) >> 7) & k01;
+    const u32 l = ((lost0 | lost1) >> 7) & k01;
+    return k01 + (w << 1) + l;
+}
+
+template <int S>
+__global__ __launch_bounds__(kBlock) void k_tally_votes_small(
+    const uint8_t* __restrict__ votes, u64 stride, const uint8_t* __restrict__ in_mask,
+    const uint8_t* __restrict__ out_mask, const uint8_t* __restrict__ learner_mask, u32 uniform_voters,
+    uint8_t* __restrict__ result, uint8_t* __restrict__ granted, uint8_t* __restrict__ rejected) {
+    const u64 g0 = ((u64)blockIdx.x * kBlock + threadIdx.x) * 16;
+    Vec<u32, 4> cell[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) cell[s] = load_vec<u32, 4>(reinterpret_cast<const u32*>(votes + (u64)s * stride + g0));
+    Vec<u32, 4> M0, M1, ML;
+    if (in_mask) {
+        M0 = load_vec<u32, 4>(reinterpret_cast<const u32*>(in_mask + g0));
+        M1 = load_vec<u32, 4>(reinterpret_cast<const u32*>(out_mask + g0));
+        if (learner_mask) ML = load_vec<u32, 4>(reinterpret_cast<const u32*>(learner_mask + g0));
+    }
+    const u32 slots = (1u << S) - 1u;
+    Vec<u32, 4> res, gr, rj;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        u32 m0, m1, ml;
+        if (in_mask) {
+            m0 = M0.v[w] & (slots * k01);
+            m1 = M1.v[w] & (slots * k01);
+            ml = learner_mask ? ML.v[w] : 0u;
+        } else {
+            const u32 vm = (uniform_voters >= 8 ? 0xFFu : ((1u << uniform_voters) - 1u)) & slots;
+            m0 = vm * k01;
+            m1 = 0;
+            ml = (slots & ~vm) * k01;
+        }
+        u32 yes0 = 0, no0 = 0, yes1 = 0, no1 = 0, g = 0, r = 0;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const u32 c = cell[s].v[w];
+            const u32 y = (c >> 1) & k01, n = c & ~(c >> 1) & k01;  // cell 2 = granted, 1 = rejected
+            const u32 in0 = (m0 >> s) & k01, in1 = (m1 >> s) & k01, nl = ~(ml >> s) & k01;
+            yes0 += y & in0;
+            no0 += n & in0;
+            yes1 += y & in1;
+            no1 += n & in1;
+            g += y & nl;  // tracker/tracker.go:274-287
+            r += n & nl;
+        }
+        u32 w0, l0, w1, l1;
+        swar_vote_half(swar_popc8(m0), yes0, no0, w0, l0);
+        swar_vote_half(swar_popc8(m1), yes1, no1, w1, l1);
+        res.v[w] = swar_joint(w0, l0, w1, l1);
+        gr.v[w] = g;
+        rj.v[w] = r;
+    }
+    store_vec<u32, 4>(reinterpret_cast<u32*>(result + g0), res);
+    if (granted) store_vec<u32, 4>(reinterpret_cast<u32*>(granted + g0), gr);
+    if (rejected) store_vec<u32, 4>(reinterpret_cast<u32*>(rejected + g0), rj);
+}
+
+// QuorumActive (ACKS=false: output bool, tracker/tracker.go:217-227) and the
+// ReadIndex ack quorum (ACKS=true: output VoteResult, raft.go:1552 +
+// read_only.go:68-76) from one yes-bitmask per group.
+//  - QuorumActive: every non-learner row votes its RecentActive bit, so a voter
+//    is never "missing": a half is Won iff yes >= q, else Lost.
+//  - Acks: the map only ever holds true, so a half is Won or Pending.
+template <bool ACKS>
+__global__ __launch_bounds__(kBlock) void k_tally_bits_small(
+    const uint8_t* __restrict__ bits, const uint8_t* __restrict__ in_mask,
+    const uint8_t* __restrict__ out_mask, const uint8_t* __restrict__ learner_mask, u32 S,
+    u32 uniform_voters, uint8_t* __restrict__ out) {
+    const u64 g0 = ((u64)blockIdx.x * kBlock + threadIdx.x) * 16;
+    const Vec<u32, 4> B = load_vec<u32, 4>(reinterpret_cast<const u32*>(bits + g0));
+    Vec<u32, 4> M0, M1, ML;
+    if (in_mask) {
+        M0 = load_vec<u32, 4>(reinterpret_cast<const u32*>(in_mask + g0));
+        M1 = load_vec<u32, 4>(reinterpret_cast<const u32*>(out_mask + g0));
+        if (!ACKS && learner_mask) ML = load_vec<u32, 4>(reinterpret_cast<const u32*>(learner_mask + g0));
+    }
+    const u32 slots = (S >= 8 ? 0xFFu : ((1u << S) - 1u));
+    Vec<u32, 4> res;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        u32 m0, m1, yes = B.v[w];
+        if (in_mask) {
+            m0 = M0.v[w] & (slots * k01);
+            m1 = M1.v[w] & (slots * k01);
+            if (!ACKS && learner_mask) yes &= ~ML.v[w];  // learners cast no vote (:220-222)
+        } else {
+            m0 = ((uniform_voters >= 8 ? 0xFFu : ((1u << uniform_voters) - 1u)) & slots) * k01;
+            m1 = 0;
+        }
+        const u32 n0 = swar_popc8(m0), n1 = swar_popc8(m1);
+        const u32 y0 = swar_popc8(yes & m0), y1 = swar_popc8(yes & m1);
+        u32 w0, l0, w1, l1;
+        // ACKS: no = 0 (never Lost).  QuorumActive: no = n - yes (never Pending).
+        swar_vote_half(n0, y0, ACKS ? 0u : n0 - y0, w0, l0);
+        swar_vote_half(n1, y1, ACKS ? 0u : n1 - y1, w1, l1);
+        if (ACKS) {
+            res.v[w] = swar_joint(w0, l0, w1, l1);
+        } else {
+            res.v[w] = ((w0 & w1) >> 7) & k01;  // == VoteWon
+        }
+    }
+    store_vec<u32, 4>(reinterpret_cast<u32*>(out + g0), res);
+}
+
+// ---------------------------------------------------------------------------
+// K3, wide slots (9..64): one lane per group, popcount on the 64-bit masks.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int vote_half(u64 m, u64 yes, u64 no) {
+    const int n = __popcll(m);
+    if (n == 0) return 3;
+    const int q = n / 2 + 1;
+    const int y = __popcll(yes & m), x = __popcll(no & m);
+    if (y >= q) return 3;
+    if (n - x >= q) return 1;
+    return 2;
+}
+__device__ __forceinline__ int vote_joint(int r1, int r2) {
+    if (r1 == r2) return r1;
+    if (r1 == 2 || r2 == 2) return 2;
+    return 1;
+}
+
+template <typename MaskT>
+__global__ __launch_bounds__(kBlock) void k_tally_votes_wide(
+    const uint8_t* __restrict__ votes, u64 stride, u64 G, int S, const MaskT* __restrict__ in_mask,
+    const MaskT* __restrict__ out_mask, const MaskT* __restrict__ learner_mask, int uniform_voters,
+    uint8_t* __restrict__ result, uint8_t* __restrict__ granted, uint8_t* __restrict__ rejected) {
+    const u64 g = (u64)blockIdx.x * kBlock + threadIdx.x;
+    if (g >= G) return;
+    const u64 slots = S >= 64 ? kU64Max : ((1ull << S) - 1ull);
+    u64 m0, m1, ml;
+    if (in_mask) {
+        m0 = (u64)in_mask[g] & slots;
+        m1 = (u64)out_mask[g] & slots;
+        ml = learner_mask ? (u64)learner_mask[g] : 0ull;
+    } else {
+        m0 = (uniform_voters >= 64 ? kU64Max : ((1ull << uniform_voters) - 1ull)) & slots;
+        m1 = 0;
+        ml = slots & ~m0;
+    }
+    u64 yes = 0, no = 0;
+    for (int s = 0; s < S; ++s) {
+        const u32 c = votes[(u64)s * stride + g];
+        yes |= (u64)(c == 2) << s;
+        no |= (u64)(c == 1) << s;
+    }
+    result[g] = (uint8_t)vote_joint(vote_half(m0, yes, no), vote_half(m1, yes, no));
+    if (granted) granted[g] = (uint8_t)__popcll(yes & ~ml);
+    if (rejected) rejected[g] = (uint8_t)__popcll(no & ~ml);
+}
+
+template <typename MaskT, bool ACKS>
+__global__ __launch_bounds__(kBlock) void k_tally_bits_wide(
+    const MaskT* __restrict__ bits, u64 G, int S, const MaskT* __restrict__ in_mask,
+    const MaskT* __restrict__ out_mask, const MaskT* __restrict__ learner_mask, int uniform_voters,
+    uint8_t* __restrict__ out) {
+    const u64 g = (u64)blockIdx.x * kBlock + threadIdx.x;
+    if (g >= G) return;
+    const u64 slots = S >= 64 ? kU64Max : ((1ull << S) - 1ull);
+    u64 m0, m1, yes = (u64)bits[g];
+    if (in_mask) {
+        m0 = (u64)in_mask[g] & slots;
+        m1 = (u64)out_mask[g] & slots;
+        if (!ACKS && learner_mask) yes &= ~(u64)learner_mask[g];
+    } else {
+        m0 = (uniform_voters >= 64 ? kU64Max : ((1ull << uniform_voters) - 1ull)) & slots;
+        m1 = 0;
+    }
+    const u64 no = ACKS ? 0ull : ~yes;
+    const int r = vote_joint(vote_half(m0, yes, no), vote_half(m1, yes, no));
+    out[g] = ACKS ? (uint8_t)r : (uint8_t)(r == 3);
+}
+
+}  // namespace rafthip

@@ -1,0 +1,831 @@
+// rafthip.hip — host side of librafthip.so: the engine object, kernel dispatch
+// and the C ABI declared in include/rafthip.h.  No torch, no CPU compute path:
+// every result comes from the gfx950 kernels in kernels.h.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "kernels.h"
+#include "rafthip.h"
+
+using namespace rafthip;
+
+static_assert(sizeof(Pair) == sizeof(rafthip_commit_pair), "pair layout");
+static_assert(sizeof(Ack) == sizeof(rafthip_ack), "ack layout");
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess)                                                                 \
+            return fail(_e == hipErrorOutOfMemory ? RAFTHIP_ENOMEM : RAFTHIP_EIO, "%s: %s",   \
+                        #expr, hipGetErrorString(_e));                                        \
+    } while (0)
+
+u64 round_up(u64 x, u64 a) { return (x + a - 1) / a * a; }
+
+int mask_bytes_for(u32 S) { return S <= 8 ? 1 : S <= 16 ? 2 : S <= 32 ? 4 : 8; }
+
+}  // namespace
+
+struct rafthip_engine {
+    int device = 0;
+    u64 G = 0;
+    u32 S = 0;
+    u64 stride = 0;  // elements per plane row (multiple of kPlaneAlign)
+    int mbytes = 1;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+
+    // config
+    bool uniform = true;
+    u32 uniform_voters = 0;
+    void* in_mask = nullptr;
+    void* out_mask = nullptr;
+    void* learner_mask = nullptr;
+    bool have_learners = false;
+
+    // state planes
+    u64* match = nullptr;
+    u64* commit = nullptr;
+    uint8_t* votes = nullptr;
+    void* active = nullptr;
+    void* acks = nullptr;
+
+    // outputs
+    uint8_t* vote_result = nullptr;
+    uint8_t* granted = nullptr;
+    uint8_t* rejected = nullptr;
+    uint8_t* qactive = nullptr;
+    uint8_t* ack_result = nullptr;
+
+    // changed-pair compaction
+    Pair* stage = nullptr;
+    Pair* packed = nullptr;
+    u32* counts = nullptr;
+    u64* offsets = nullptr;
+    u32 counts_cap = 0;
+
+    // scatter
+    Ack* ack_buf = nullptr;
+    u64 ack_cap = 0;
+    u64* d_rejected = nullptr;
+    u64* h_scalar = nullptr;  // pinned, 2 x u64
+
+    rafthip_stats_t stats{};
+};
+
+namespace {
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        ok = (hipSetDevice(dev) == hipSuccess);
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+int check_range(const rafthip_engine* e, u64 first, u64 count) {
+    if (!e) return fail(RAFTHIP_EINVAL, "engine is NULL");
+    if (first > e->G || count > e->G - first)
+        return fail(RAFTHIP_ERANGE, "group range [%llu, +%llu) outside [0, %llu)", first, count, e->G);
+    return RAFTHIP_OK;
+}
+
+template <typename T>
+int ensure(rafthip_engine* e, T*& p, size_t bytes, bool zero = true) {
+    if (p) return RAFTHIP_OK;
+    void* q = nullptr;
+    HIP_TRY(hipMalloc(&q, bytes));
+    if (zero) HIP_TRY(hipMemsetAsync(q, 0, bytes, e->stream));
+    p = static_cast<T*>(q);
+    return RAFTHIP_OK;
+}
+
+int ensure_masks(rafthip_engine* e) {
+    const size_t b = (size_t)e->stride * e->mbytes;
+    int rc;
+    if ((rc = ensure(e, e->in_mask, b))) return rc;
+    if ((rc = ensure(e, e->out_mask, b))) return rc;
+    if ((rc = ensure(e, e->learner_mask, b))) return rc;
+    return RAFTHIP_OK;
+}
+
+// 2-D copy of `rows` plane segments of `count` elements each.
+int copy_rows(rafthip_engine* e, void* dst, u64 dst_stride_b, const void* src, u64 src_stride_b,
+              u64 width_b, u64 rows) {
+    if (width_b == 0 || rows == 0) return RAFTHIP_OK;
+    HIP_TRY(hipMemcpy2DAsync(dst, dst_stride_b, src, src_stride_b, width_b, rows, hipMemcpyDefault,
+                             e->stream));
+    return RAFTHIP_OK;
+}
+
+// ---- kernel dispatch -----------------------------------------------------
+
+constexpr int kGPT = 2;  // groups per lane in K1/K2: one 16-byte access per plane
+
+template <bool CHANGED>
+int launch_commit(rafthip_engine* e, u32* block_groups) {
+    const u64 G = e->G;
+    hipStream_t st = e->stream;
+    if (e->uniform && e->uniform_voters == 0) {
+        // Both halves empty: MaxUint64 for every group (majority.go:128-132).
+        // Expressed through the masked kernel with all-zero masks.
+        int rc = ensure_masks(e);
+        if (rc) return rc;
+    }
+    const bool uni = e->uniform && e->uniform_voters > 0;
+    if (e->S <= 8) {
+        const u32 blocks = (u32)((G + (u64)kBlock * kGPT - 1) / ((u64)kBlock * kGPT));
+        *block_groups = kBlock * kGPT;
+        if (CHANGED && blocks > e->counts_cap) return fail(RAFTHIP_EINVAL, "internal: counts capacity");
+        if (uni) {
+            switch (e->uniform_voters) {
+#define RAFTHIP_CASE_U(V)                                                                          \
+    case V:                                                                                        \
+        hipLaunchKernelGGL((k_commit_uniform<V, kGPT, CHANGED>), dim3(blocks), dim3(kBlock), 0, st, \
+                           e->match, e->stride, G, e->commit, e->stage, e->counts);                \
+        break;
+                RAFTHIP_CASE_U(1) RAFTHIP_CASE_U(2) RAFTHIP_CASE_U(3) RAFTHIP_CASE_U(4)
+                RAFTHIP_CASE_U(5) RAFTHIP_CASE_U(6) RAFTHIP_CASE_U(7) RAFTHIP_CASE_U(8)
+#undef RAFTHIP_CASE_U
+                default: return fail(RAFTHIP_EINVAL, "internal: uniform voters %u", e->uniform_voters);
+            }
+        } else {
+            const uint8_t* m0 = static_cast<const uint8_t*>(e->in_mask);
+            const uint8_t* m1 = static_cast<const uint8_t*>(e->out_mask);
+            switch (e->S) {
+#define RAFTHIP_CASE_M(SS)                                                                         \
+    case SS:                                                                                       \
+        hipLaunchKernelGGL((k_commit_masked<SS, kGPT, CHANGED>), dim3(blocks), dim3(kBlock), 0, st, \
+                           e->match, e->stride, G, m0, m1, e->commit, e->stage, e->counts);        \
+        break;
+                RAFTHIP_CASE_M(1) RAFTHIP_CASE_M(2) RAFTHIP_CASE_M(3) RAFTHIP_CASE_M(4)
+                RAFTHIP_CASE_M(5) RAFTHIP_CASE_M(6) RAFTHIP_CASE_M(7) RAFTHIP_CASE_M(8)
+#undef RAFTHIP_CASE_M
+                default: return fail(RAFTHIP_EINVAL, "internal: slots %u", e->S);
+            }
+        }
+    } else {
+        const u32 blocks = (u32)((G + kBlock - 1) / kBlock);
+        *block_groups = kBlock;
+        if (CHANGED && blocks > e->counts_cap) return fail(RAFTHIP_EINVAL, "internal: counts capacity");
+        const size_t lds = (size_t)(kBlock / 64) * e->S * kTileStride * sizeof(u64);
+        const int uv = uni ? (int)e->uniform_voters : 0;
+#define RAFTHIP_WIDE(W, MT)                                                                        \
+    hipLaunchKernelGGL((k_commit_wide<W, MT, CHANGED>), dim3(blocks), dim3(kBlock), lds, st,       \
+                       e->match, e->stride, G, (int)e->S,                                          \
+                       uni ? nullptr : static_cast<const MT*>(e->in_mask),                         \
+                       uni ? nullptr : static_cast<const MT*>(e->out_mask), uv, e->commit,         \
+                       e->stage, e->counts)
+        if (e->S <= 16) {
+            RAFTHIP_WIDE(16, uint16_t);
+        } else if (e->S <= 32) {
+            RAFTHIP_WIDE(32, uint32_t);
+        } else {
+            RAFTHIP_WIDE(64, uint64_t);
+        }
+#undef RAFTHIP_WIDE
+    }
+    HIP_TRY(hipGetLastError());
+    e->stats.commit_launches++;
+    e->stats.groups_evaluated += G;
+    return RAFTHIP_OK;
+}
+
+int ensure_changed_buffers(rafthip_engine* e) {
+    const u32 bg = e->S <= 8 ? kBlock * kGPT : kBlock;
+    const u32 blocks = (u32)((e->G + bg - 1) / bg);
+    int rc;
+    if ((rc = ensure(e, e->stage, (size_t)blocks * bg * sizeof(Pair), false))) return rc;
+    if ((rc = ensure(e, e->packed, (size_t)blocks * bg * sizeof(Pair), false))) return rc;
+    if ((rc = ensure(e, e->counts, (size_t)blocks * sizeof(u32)))) return rc;
+    if ((rc = ensure(e, e->offsets, ((size_t)blocks + 1) * sizeof(u64)))) return rc;
+    e->counts_cap = blocks;
+    return RAFTHIP_OK;
+}
+
+static int upload_bits(rafthip_engine* e, void*& plane, uint64_t first, uint64_t count, const void* src) {
+    int rc = check_range(e, first, count);
+    if (rc) return rc;
+    if (!src) return fail(RAFTHIP_EINVAL, "src is NULL");
+    DeviceGuard guard(e->device);
+    const size_t mb = (size_t)e->mbytes;
+    if ((rc = ensure(e, plane, (size_t)e->stride * mb))) return rc;
+    HIP_TRY(hipMemcpyAsync(static_cast<char*>(plane) + first * mb, src, count * mb, hipMemcpyDefault, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    e->stats.bytes_uploaded += count * mb;
+    return RAFTHIP_OK;
+}
+
+static int read_u8(rafthip_engine* e, const uint8_t* plane, const char* what, uint64_t first,
+                   uint64_t count, uint8_t* dst) {
+    if (!plane) return fail(RAFTHIP_EINVAL, "%s has not been computed yet", what);
+    HIP_TRY(hipMemcpyAsync(dst, plane + first, count, hipMemcpyDefault, e->stream));
+    e->stats.bytes_downloaded += count;
+    return RAFTHIP_OK;
+}
+
+template <bool ACKS>
+static int tally_bits(rafthip_engine* e, void* bits, uint8_t*& out, const char* what) {
+    if (!bits) return fail(RAFTHIP_EINVAL, "%s bits have not been uploaded", what);
+    int rc;
+    if ((rc = ensure(e, out, e->stride))) return rc;
+    if (e->uniform && e->uniform_voters == 0 && (rc = ensure_masks(e))) return rc;
+    const bool uni = e->uniform && e->uniform_voters > 0;
+    hipStream_t st = e->stream;
+    if (e->S <= 8) {
+        const u32 blocks = (u32)((e->G + (u64)kBlock * 16 - 1) / ((u64)kBlock * 16));
+        hipLaunchKernelGGL((k_tally_bits_small<ACKS>), dim3(blocks), dim3(kBlock), 0, st,
+                           static_cast<const uint8_t*>(bits),
+                           uni ? nullptr : static_cast<const uint8_t*>(e->in_mask),
+                           uni ? nullptr : static_cast<const uint8_t*>(e->out_mask),
+                           uni ? nullptr : static_cast<const uint8_t*>(e->learner_mask), e->S,
+                           e->uniform_voters, out);
+    } else {
+        const u32 blocks = (u32)((e->G + kBlock - 1) / kBlock);
+#define RAFTHIP_BW(MT)                                                                              \
+    hipLaunchKernelGGL((k_tally_bits_wide<MT, ACKS>), dim3(blocks), dim3(kBlock), 0, st,            \
+                       static_cast<const MT*>(bits), e->G, (int)e->S,                               \
+                       uni ? nullptr : static_cast<const MT*>(e->in_mask),                          \
+                       uni ? nullptr : static_cast<const MT*>(e->out_mask),                         \
+                       uni ? nullptr : static_cast<const MT*>(e->learner_mask),                     \
+                       (int)e->uniform_voters, out)
+        if (e->mbytes == 2) {
+            RAFTHIP_BW(uint16_t);
+        } else if (e->mbytes == 4) {
+            RAFTHIP_BW(uint32_t);
+        } else {
+            RAFTHIP_BW(uint64_t);
+        }
+#undef RAFTHIP_BW
+    }
+    HIP_TRY(hipGetLastError());
+    e->stats.groups_evaluated += e->G;
+    return RAFTHIP_OK;
+}
+
+static int oneshot_engine(int device, uint64_t G, uint32_t S, const void* in_mask, const void* out_mask,
+                          rafthip_engine** out) {
+    if (!in_mask) return fail(RAFTHIP_EINVAL, "in_mask is NULL");
+    rafthip_config cfg{};
+    cfg.struct_size = sizeof(cfg);
+    cfg.device = device;
+    cfg.num_groups = G;
+    cfg.num_slots = S;
+    rafthip_engine* e = nullptr;
+    int rc = rafthip_create(&cfg, &e);
+    if (rc) return rc;
+    if (out_mask) {
+        rc = rafthip_upload_config(e, 0, G, in_mask, out_mask, nullptr);
+    } else {
+        // non-joint: the outgoing half is the zero MajorityConfig
+        rc = ensure_masks(e);
+        if (!rc) {
+            hipError_t err = hipMemcpyAsync(e->in_mask, in_mask, G * e->mbytes, hipMemcpyDefault, e->stream);
+            if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
+            if (err != hipSuccess) rc = fail(RAFTHIP_EIO, "mask upload: %s", hipGetErrorString(err));
+            e->uniform = false;
+        }
+    }
+    if (rc) {
+        char keep[sizeof(g_err)];
+        memcpy(keep, g_err, sizeof(keep));
+        rafthip_destroy(e);
+        memcpy(g_err, keep, sizeof(keep));
+        return rc;
+    }
+    *out = e;
+    return RAFTHIP_OK;
+}
+
+}  // namespace
+
+// ==========================================================================
+// C ABI
+// ==========================================================================
+extern "C" {
+
+uint32_t rafthip_abi_version(void) { return RAFTHIP_ABI_VERSION; }
+
+const char* rafthip_last_error(void) { return g_err; }
+
+int rafthip_device_count(int* count) {
+    if (!count) return fail(RAFTHIP_EINVAL, "count is NULL");
+    int n = 0;
+    hipError_t err = hipGetDeviceCount(&n);
+    if (err != hipSuccess) {
+        *count = 0;
+        return fail(RAFTHIP_ENODEV, "hipGetDeviceCount: %s", hipGetErrorString(err));
+    }
+    *count = n;
+    return RAFTHIP_OK;
+}
+
+int rafthip_create(const rafthip_config* cfg, rafthip_engine** out) {
+    if (!cfg || !out) return fail(RAFTHIP_EINVAL, "cfg/out is NULL");
+    *out = nullptr;
+    if (cfg->struct_size < sizeof(rafthip_config))
+        return fail(RAFTHIP_EINVAL, "rafthip_config.struct_size %u < %zu", cfg->struct_size,
+                    sizeof(rafthip_config));
+    if (cfg->num_groups == 0) return fail(RAFTHIP_EINVAL, "num_groups must be >= 1");
+    if (cfg->num_groups > 0xFFFFFFFFull)
+        return fail(RAFTHIP_EINVAL, "num_groups %llu exceeds the 32-bit group id of rafthip_ack",
+                    (u64)cfg->num_groups);
+    if (cfg->num_slots == 0 || cfg->num_slots > RAFTHIP_MAX_SLOTS)
+        return fail(RAFTHIP_EINVAL, "num_slots %u outside [1, %u]", cfg->num_slots, RAFTHIP_MAX_SLOTS);
+    if (cfg->flags != 0) return fail(RAFTHIP_EINVAL, "unknown flags 0x%x", cfg->flags);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(RAFTHIP_ENODEV, "no HIP device available (this library has no CPU path)");
+    if (cfg->device < 0 || cfg->device >= ndev)
+        return fail(RAFTHIP_ENODEV, "device %d outside [0, %d)", cfg->device, ndev);
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, cfg->device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(RAFTHIP_ENODEV, "device %d is %s; librafthip.so carries gfx950 code only",
+                    cfg->device, prop.gcnArchName);
+
+    DeviceGuard guard(cfg->device);
+    if (!guard.ok) return fail(RAFTHIP_ENODEV, "hipSetDevice(%d) failed", cfg->device);
+    rafthip_engine* e = new (std::nothrow) rafthip_engine();
+    if (!e) return fail(RAFTHIP_ENOMEM, "host allocation failed");
+    e->device = cfg->device;
+    e->G = cfg->num_groups;
+    e->S = cfg->num_slots;
+    e->stride = round_up(e->G, kPlaneAlign);
+    e->mbytes = mask_bytes_for(e->S);
+    int rc = RAFTHIP_OK;
+    do {
+        if (cfg->stream) {
+            e->stream = static_cast<hipStream_t>(cfg->stream);
+        } else {
+            hipError_t err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+            if (err != hipSuccess) {
+                rc = fail(RAFTHIP_EIO, "hipStreamCreate: %s", hipGetErrorString(err));
+                break;
+            }
+            e->own_stream = true;
+        }
+        if ((rc = ensure(e, e->match, (size_t)e->S * e->stride * sizeof(u64)))) break;
+        if ((rc = ensure(e, e->commit, (size_t)e->stride * sizeof(u64)))) break;
+        if ((rc = ensure(e, e->d_rejected, sizeof(u64)))) break;
+        hipError_t err = hipHostMalloc(reinterpret_cast<void**>(&e->h_scalar), 2 * sizeof(u64), hipHostMallocDefault);
+        if (err != hipSuccess) {
+            rc = fail(RAFTHIP_ENOMEM, "hipHostMalloc: %s", hipGetErrorString(err));
+            break;
+        }
+        err = hipStreamSynchronize(e->stream);
+        if (err != hipSuccess) rc = fail(RAFTHIP_EIO, "hipStreamSynchronize: %s", hipGetErrorString(err));
+    } while (0);
+    if (rc) {
+        char keep[sizeof(g_err)];
+        memcpy(keep, g_err, sizeof(keep));
+        rafthip_destroy(e);
+        memcpy(g_err, keep, sizeof(keep));
+        return rc;
+    }
+    *out = e;
+    return RAFTHIP_OK;
+}
+
+int rafthip_destroy(rafthip_engine* e) {
+    if (!e) return RAFTHIP_OK;
+    DeviceGuard guard(e->device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    void* bufs[] = {e->in_mask, e->out_mask,   e->learner_mask, e->match,    e->commit, e->votes,
+                    e->active,  e->acks,       e->vote_result,  e->granted,  e->rejected, e->qactive,
+                    e->ack_result, e->stage,   e->packed,       e->counts,   e->offsets,  e->ack_buf,
+                    e->d_rejected};
+    for (void* b : bufs)
+        if (b) (void)hipFree(b);
+    if (e->h_scalar) (void)hipHostFree(e->h_scalar);
+    if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+    return RAFTHIP_OK;
+}
+
+int rafthip_synchronize(rafthip_engine* e) {
+    if (!e) return fail(RAFTHIP_EINVAL, "engine is NULL");
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return RAFTHIP_OK;
+}
+
+int rafthip_mask_bytes(const rafthip_engine* e) { return e ? e->mbytes : RAFTHIP_EINVAL; }
+
+int rafthip_stats(rafthip_engine* e, rafthip_stats_t* out) {
+    if (!e || !out) return fail(RAFTHIP_EINVAL, "engine/out is NULL");
+    DeviceGuard guard(e->device);
+    HIP_TRY(hipMemcpyAsync(e->h_scalar, e->d_rejected, sizeof(u64), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    e->stats.acks_rejected = e->h_scalar[0];
+    *out = e->stats;
+    return RAFTHIP_OK;
+}
+
+// ---- configuration -------------------------------------------------------
+
+int rafthip_set_uniform_config(rafthip_engine* e, uint32_t voters) {
+    if (!e) return fail(RAFTHIP_EINVAL, "engine is NULL");
+    if (voters > e->S) return fail(RAFTHIP_EINVAL, "voters %u > num_slots %u", voters, e->S);
+    e->uniform = true;
+    e->uniform_voters = voters;
+    if (voters == 0 && e->in_mask) {
+        DeviceGuard guard(e->device);
+        const size_t b = (size_t)e->stride * e->mbytes;
+        HIP_TRY(hipMemsetAsync(e->in_mask, 0, b, e->stream));
+        HIP_TRY(hipMemsetAsync(e->out_mask, 0, b, e->stream));
+        HIP_TRY(hipMemsetAsync(e->learner_mask, 0, b, e->stream));
+    }
+    return RAFTHIP_OK;
+}
+
+int rafthip_upload_config(rafthip_engine* e, uint64_t first, uint64_t count, const void* in_mask,
+                          const void* out_mask, const void* learner_mask) {
+    int rc = check_range(e, first, count);
+    if (rc) return rc;
+    if (!in_mask || !out_mask) return fail(RAFTHIP_EINVAL, "in_mask/out_mask is NULL");
+    DeviceGuard guard(e->device);
+    const bool had = e->in_mask != nullptr;
+    if ((rc = ensure_masks(e))) return rc;
+    const size_t mb = (size_t)e->mbytes;
+    if (e->uniform && e->uniform_voters > 0 && (first != 0 || count != e->G)) {
+        // Switching from the uniform fast path with a partial upload: the rest
+        // of the groups keep the uniform config, so materialise it first.
+        const u64 vm = e->uniform_voters >= 64 ? ~0ull : ((1ull << e->uniform_voters) - 1ull);
+        const u64 lm = (e->S >= 64 ? ~0ull : ((1ull << e->S) - 1ull)) & ~vm;
+        // byte-pattern fill only works for 1-byte masks; wider masks go through a host staging row
+        if (mb == 1) {
+            HIP_TRY(hipMemsetAsync(e->in_mask, (int)(vm & 0xFF), e->stride, e->stream));
+            HIP_TRY(hipMemsetAsync(e->out_mask, 0, e->stride, e->stream));
+            HIP_TRY(hipMemsetAsync(e->learner_mask, (int)(lm & 0xFF), e->stride, e->stream));
+        } else {
+            const size_t bytes = (size_t)e->G * mb;
+            unsigned char* tmp = new (std::nothrow) unsigned char[bytes * 2];
+            if (!tmp) return fail(RAFTHIP_ENOMEM, "host allocation failed");
+            for (u64 g = 0; g < e->G; ++g) {
+                memcpy(tmp + g * mb, &vm, mb);
+                memcpy(tmp + bytes + g * mb, &lm, mb);
+            }
+            hipError_t e1 = hipMemcpyAsync(e->in_mask, tmp, bytes, hipMemcpyHostToDevice, e->stream);
+            hipError_t e2 = hipMemcpyAsync(e->learner_mask, tmp + bytes, bytes, hipMemcpyHostToDevice, e->stream);
+            (void)hipStreamSynchronize(e->stream);
+            delete[] tmp;
+            HIP_TRY(e1);
+            HIP_TRY(e2);
+            HIP_TRY(hipMemsetAsync(e->out_mask, 0, (size_t)e->stride * mb, e->stream));
+        }
+    }
+    (void)had;
+    char* d0 = static_cast<char*>(e->in_mask) + first * mb;
+    char* d1 = static_cast<char*>(e->out_mask) + first * mb;
+    char* d2 = static_cast<char*>(e->learner_mask) + first * mb;
+    HIP_TRY(hipMemcpyAsync(d0, in_mask, count * mb, hipMemcpyDefault, e->stream));
+    HIP_TRY(hipMemcpyAsync(d1, out_mask, count * mb, hipMemcpyDefault, e->stream));
+    if (learner_mask) {
+        HIP_TRY(hipMemcpyAsync(d2, learner_mask, count * mb, hipMemcpyDefault, e->stream));
+        e->have_learners = true;
+    } else {
+        HIP_TRY(hipMemsetAsync(d2, 0, count * mb, e->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(e->stream));  // source buffers may be pageable host memory
+    e->uniform = false;
+    e->stats.bytes_uploaded += count * mb * (learner_mask ? 3 : 2);
+    return RAFTHIP_OK;
+}
+
+// ---- state ---------------------------------------------------------------
+
+int rafthip_upload_match(rafthip_engine* e, uint64_t first, uint64_t count, const uint64_t* src,
+                         uint64_t src_stride) {
+    int rc = check_range(e, first, count);
+    if (rc) return rc;
+    if (!src) return fail(RAFTHIP_EINVAL, "src is NULL");
+    if (src_stride < count) return fail(RAFTHIP_EINVAL, "src_stride %llu < count %llu", (u64)src_stride, (u64)count);
+    DeviceGuard guard(e->device);
+    if ((rc = copy_rows(e, e->match + first, e->stride * 8, src, src_stride * 8, count * 8, e->S))) return rc;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    e->stats.bytes_uploaded += count * 8 * e->S;
+    return RAFTHIP_OK;
+}
+
+int rafthip_reset_match(rafthip_engine* e, uint64_t first, uint64_t count) {
+    int rc = check_range(e, first, count);
+    if (rc) return rc;
+    if (count == 0) return RAFTHIP_OK;
+    DeviceGuard guard(e->device);
+    HIP_TRY(hipMemset2DAsync(e->match + first, e->stride * 8, 0, count * 8, e->S, e->stream));
+    return RAFTHIP_OK;
+}
+
+int rafthip_read_match(rafthip_engine* e, uint64_t first, uint64_t count, uint64_t* dst,
+                       uint64_t dst_stride) {
+    int rc = check_range(e, first, count);
+    if (rc) return rc;
+    if (!dst) return fail(RAFTHIP_EINVAL, "dst is NULL");
+    if (dst_stride < count) return fail(RAFTHIP_EINVAL, "dst_stride %llu < count %llu", (u64)dst_stride, (u64)count);
+    DeviceGuard guard(e->device);
+    if ((rc = copy_rows(e, dst, dst_stride * 8, e->match + first, e->stride * 8, count * 8, e->S))) return rc;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    e->stats.bytes_downloaded += count * 8 * e->S;
+    return RAFTHIP_OK;
+}
+
+int rafthip_upload_votes(rafthip_engine* e, uint64_t first, uint64_t count, const uint8_t* src,
+                         uint64_t src_stride) {
+    int rc = check_range(e, first, count);
+    if (rc) return rc;
+    if (!src) return fail(RAFTHIP_EINVAL, "src is NULL");
+    if (src_stride < count) return fail(RAFTHIP_EINVAL, "src_stride %llu < count %llu", (u64)src_stride, (u64)count);
+    DeviceGuard guard(e->device);
+    if ((rc = ensure(e, e->votes, (size_t)e->S * e->stride))) return rc;
+    if ((rc = copy_rows(e, e->votes + first, e->stride, src, src_stride, count, e->S))) return rc;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    e->stats.bytes_uploaded += count * e->S;
+    return RAFTHIP_OK;
+}
+
+int rafthip_reset_votes(rafthip_engine* e, uint64_t first, uint64_t count) {
+    int rc = check_range(e, first, count);
+    if (rc) return rc;
+    DeviceGuard guard(e->device);
+    if ((rc = ensure(e, e->votes, (size_t)e->S * e->stride))) return rc;
+    if (count == 0) return RAFTHIP_OK;
+    HIP_TRY(hipMemset2DAsync(e->votes + first, e->stride, 0, count, e->S, e->stream));
+    return RAFTHIP_OK;
+}
+
+int rafthip_upload_active(rafthip_engine* e, uint64_t first, uint64_t count, const void* src) {
+    if (!e) return fail(RAFTHIP_EINVAL, "engine is NULL");
+    return upload_bits(e, e->active, first, count, src);
+}
+
+int rafthip_upload_acks(rafthip_engine* e, uint64_t first, uint64_t count, const void* src) {
+    if (!e) return fail(RAFTHIP_EINVAL, "engine is NULL");
+    return upload_bits(e, e->acks, first, count, src);
+}
+
+int rafthip_upload_commit(rafthip_engine* e, uint64_t first, uint64_t count, const uint64_t* src) {
+    int rc = check_range(e, first, count);
+    if (rc) return rc;
+    if (!src) return fail(RAFTHIP_EINVAL, "src is NULL");
+    DeviceGuard guard(e->device);
+    HIP_TRY(hipMemcpyAsync(e->commit + first, src, count * 8, hipMemcpyDefault, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    e->stats.bytes_uploaded += count * 8;
+    return RAFTHIP_OK;
+}
+
+// ---- compute -------------------------------------------------------------
+
+int rafthip_scatter_acks(rafthip_engine* e, const rafthip_ack* recs, uint64_t n) {
+    if (!e) return fail(RAFTHIP_EINVAL, "engine is NULL");
+    if (n == 0) return RAFTHIP_OK;
+    if (!recs) return fail(RAFTHIP_EINVAL, "recs is NULL");
+    if (n > 0xFFFFFFFFull * kBlock) return fail(RAFTHIP_EINVAL, "too many acks in one call");
+    DeviceGuard guard(e->device);
+    hipPointerAttribute_t attr;
+    const Ack* d_recs = nullptr;
+    bool staged = false;
+    if (hipPointerGetAttributes(&attr, recs) == hipSuccess && attr.type == hipMemoryTypeDevice) {
+        d_recs = reinterpret_cast<const Ack*>(recs);
+    } else {
+        (void)hipGetLastError();  // plain host memory reports an error on some runtimes
+        if (e->ack_cap < n) {
+            if (e->ack_buf) {
+                HIP_TRY(hipStreamSynchronize(e->stream));
+                HIP_TRY(hipFree(e->ack_buf));
+                e->ack_buf = nullptr;
+                e->ack_cap = 0;
+            }
+            void* q = nullptr;
+            HIP_TRY(hipMalloc(&q, n * sizeof(Ack)));
+            e->ack_buf = static_cast<Ack*>(q);
+            e->ack_cap = n;
+        }
+        HIP_TRY(hipMemcpyAsync(e->ack_buf, recs, n * sizeof(Ack), hipMemcpyHostToDevice, e->stream));
+        d_recs = e->ack_buf;
+        staged = true;
+        e->stats.bytes_uploaded += n * sizeof(Ack);
+    }
+    const u32 blocks = (u32)((n + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(k_scatter_acks, dim3(blocks), dim3(kBlock), 0, e->stream, e->match, e->stride, e->G,
+                       e->S, d_recs, (u64)n, e->d_rejected);
+    HIP_TRY(hipGetLastError());
+    if (staged) HIP_TRY(hipStreamSynchronize(e->stream));  // caller may reuse its host buffer
+    e->stats.acks_applied += n;
+    return RAFTHIP_OK;
+}
+
+int rafthip_commit(rafthip_engine* e) {
+    if (!e) return fail(RAFTHIP_EINVAL, "engine is NULL");
+    DeviceGuard guard(e->device);
+    u32 bg = 0;
+    return launch_commit<false>(e, &bg);
+}
+
+int rafthip_commit_changed(rafthip_engine* e, rafthip_commit_pair* dst, uint64_t max_pairs,
+                           uint64_t* n_changed) {
+    if (!e || !n_changed) return fail(RAFTHIP_EINVAL, "engine/n_changed is NULL");
+    if (max_pairs > 0 && !dst) return fail(RAFTHIP_EINVAL, "dst is NULL with max_pairs > 0");
+    DeviceGuard guard(e->device);
+    int rc = ensure_changed_buffers(e);
+    if (rc) return rc;
+    u32 bg = 0;
+    if ((rc = launch_commit<true>(e, &bg))) return rc;
+    const u32 blocks = (u32)((e->G + bg - 1) / bg);
+    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, e->stream, e->counts, blocks, e->offsets);
+    hipLaunchKernelGGL(k_pack_pairs, dim3(blocks), dim3(kBlock), 0, e->stream, e->stage, e->counts,
+                       e->offsets, bg, e->packed);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(e->h_scalar + 1, e->offsets + blocks, sizeof(u64), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    const u64 total = e->h_scalar[1];
+    *n_changed = total;
+    const u64 ncopy = total < max_pairs ? total : max_pairs;
+    if (ncopy) {
+        HIP_TRY(hipMemcpyAsync(dst, e->packed, ncopy * sizeof(Pair), hipMemcpyDefault, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        e->stats.bytes_downloaded += ncopy * sizeof(Pair);
+    }
+    e->stats.changed_reported += total;
+    return RAFTHIP_OK;
+}
+
+int rafthip_read_commit(rafthip_engine* e, uint64_t first, uint64_t count, uint64_t* dst) {
+    int rc = check_range(e, first, count);
+    if (rc) return rc;
+    if (!dst) return fail(RAFTHIP_EINVAL, "dst is NULL");
+    DeviceGuard guard(e->device);
+    HIP_TRY(hipMemcpyAsync(dst, e->commit + first, count * 8, hipMemcpyDefault, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    e->stats.bytes_downloaded += count * 8;
+    return RAFTHIP_OK;
+}
+
+int rafthip_tally_votes(rafthip_engine* e) {
+    if (!e) return fail(RAFTHIP_EINVAL, "engine is NULL");
+    DeviceGuard guard(e->device);
+    int rc;
+    if ((rc = ensure(e, e->votes, (size_t)e->S * e->stride))) return rc;
+    if ((rc = ensure(e, e->vote_result, e->stride))) return rc;
+    if ((rc = ensure(e, e->granted, e->stride))) return rc;
+    if ((rc = ensure(e, e->rejected, e->stride))) return rc;
+    if (e->uniform && e->uniform_voters == 0 && (rc = ensure_masks(e))) return rc;
+    const bool uni = e->uniform && e->uniform_voters > 0;
+    hipStream_t st = e->stream;
+    if (e->S <= 8) {
+        const u32 blocks = (u32)((e->G + (u64)kBlock * 16 - 1) / ((u64)kBlock * 16));
+        const uint8_t* m0 = uni ? nullptr : static_cast<const uint8_t*>(e->in_mask);
+        const uint8_t* m1 = uni ? nullptr : static_cast<const uint8_t*>(e->out_mask);
+        const uint8_t* ml = uni ? nullptr : static_cast<const uint8_t*>(e->learner_mask);
+        switch (e->S) {
+#define RAFTHIP_CASE_T(SS)                                                                          \
+    case SS:                                                                                        \
+        hipLaunchKernelGGL((k_tally_votes_small<SS>), dim3(blocks), dim3(kBlock), 0, st, e->votes,   \
+                           e->stride, m0, m1, ml, e->uniform_voters, e->vote_result, e->granted,    \
+                           e->rejected);                                                            \
+        break;
+            RAFTHIP_CASE_T(1) RAFTHIP_CASE_T(2) RAFTHIP_CASE_T(3) RAFTHIP_CASE_T(4)
+            RAFTHIP_CASE_T(5) RAFTHIP_CASE_T(6) RAFTHIP_CASE_T(7) RAFTHIP_CASE_T(8)
+#undef RAFTHIP_CASE_T
+        }
+    } else {
+        const u32 blocks = (u32)((e->G + kBlock - 1) / kBlock);
+#define RAFTHIP_TW(MT)                                                                               \
+    hipLaunchKernelGGL((k_tally_votes_wide<MT>), dim3(blocks), dim3(kBlock), 0, st, e->votes, e->stride, \
+                       e->G, (int)e->S, uni ? nullptr : static_cast<const MT*>(e->in_mask),          \
+                       uni ? nullptr : static_cast<const MT*>(e->out_mask),                          \
+                       uni ? nullptr : static_cast<const MT*>(e->learner_mask),                      \
+                       (int)e->uniform_voters, e->vote_result, e->granted, e->rejected)
+        if (e->mbytes == 2) {
+            RAFTHIP_TW(uint16_t);
+        } else if (e->mbytes == 4) {
+            RAFTHIP_TW(uint32_t);
+        } else {
+            RAFTHIP_TW(uint64_t);
+        }
+#undef RAFTHIP_TW
+    }
+    HIP_TRY(hipGetLastError());
+    e->stats.groups_evaluated += e->G;
+    return RAFTHIP_OK;
+}
+
+int rafthip_read_vote_result(rafthip_engine* e, uint64_t first, uint64_t count, uint8_t* result,
+                             uint8_t* granted, uint8_t* rejected) {
+    int rc = check_range(e, first, count);
+    if (rc) return rc;
+    if (!result) return fail(RAFTHIP_EINVAL, "result is NULL");
+    DeviceGuard guard(e->device);
+    if ((rc = read_u8(e, e->vote_result, "vote result", first, count, result))) return rc;
+    if (granted && (rc = read_u8(e, e->granted, "granted", first, count, granted))) return rc;
+    if (rejected && (rc = read_u8(e, e->rejected, "rejected", first, count, rejected))) return rc;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return RAFTHIP_OK;
+}
+
+int rafthip_quorum_active(rafthip_engine* e) {
+    if (!e) return fail(RAFTHIP_EINVAL, "engine is NULL");
+    DeviceGuard guard(e->device);
+    return tally_bits<false>(e, e->active, e->qactive, "RecentActive");
+}
+
+int rafthip_read_quorum_active(rafthip_engine* e, uint64_t first, uint64_t count, uint8_t* dst) {
+    int rc = check_range(e, first, count);
+    if (rc) return rc;
+    if (!dst) return fail(RAFTHIP_EINVAL, "dst is NULL");
+    DeviceGuard guard(e->device);
+    if ((rc = read_u8(e, e->qactive, "quorum-active", first, count, dst))) return rc;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return RAFTHIP_OK;
+}
+
+int rafthip_ack_quorum(rafthip_engine* e) {
+    if (!e) return fail(RAFTHIP_EINVAL, "engine is NULL");
+    DeviceGuard guard(e->device);
+    return tally_bits<true>(e, e->acks, e->ack_result, "ReadIndex ack");
+}
+
+int rafthip_read_ack_quorum(rafthip_engine* e, uint64_t first, uint64_t count, uint8_t* dst) {
+    int rc = check_range(e, first, count);
+    if (rc) return rc;
+    if (!dst) return fail(RAFTHIP_EINVAL, "dst is NULL");
+    DeviceGuard guard(e->device);
+    if ((rc = read_u8(e, e->ack_result, "ack-quorum", first, count, dst))) return rc;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return RAFTHIP_OK;
+}
+
+int rafthip_plane(rafthip_engine* e, int which, void** ptr, uint64_t* stride) {
+    if (!e || !ptr) return fail(RAFTHIP_EINVAL, "engine/ptr is NULL");
+    DeviceGuard guard(e->device);
+    int rc;
+    switch (which) {
+        case RAFTHIP_PLANE_MATCH: *ptr = e->match; break;
+        case RAFTHIP_PLANE_COMMIT: *ptr = e->commit; break;
+        case RAFTHIP_PLANE_VOTES:
+            if ((rc = ensure(e, e->votes, (size_t)e->S * e->stride))) return rc;
+            *ptr = e->votes;
+            break;
+        default: return fail(RAFTHIP_EINVAL, "unknown plane %d", which);
+    }
+    if (stride) *stride = e->stride;
+    return RAFTHIP_OK;
+}
+
+// ---- stateless one-shot forms ---------------------------------------------
+
+int rafthip_batch_committed_index(int device, uint64_t num_groups, uint32_t num_slots,
+                                  const uint64_t* match, const void* in_mask, const void* out_mask,
+                                  uint64_t* out) {
+    if (!match || !out) return fail(RAFTHIP_EINVAL, "match/out is NULL");
+    rafthip_engine* e = nullptr;
+    int rc = oneshot_engine(device, num_groups, num_slots, in_mask, out_mask, &e);
+    if (rc) return rc;
+    rc = rafthip_upload_match(e, 0, num_groups, match, num_groups);
+    if (!rc) rc = rafthip_commit(e);
+    if (!rc) rc = rafthip_read_commit(e, 0, num_groups, out);
+    char keep[sizeof(g_err)];
+    memcpy(keep, g_err, sizeof(keep));
+    rafthip_destroy(e);
+    memcpy(g_err, keep, sizeof(keep));
+    return rc;
+}
+
+int rafthip_batch_vote_result(int device, uint64_t num_groups, uint32_t num_slots,
+                              const uint8_t* votes, const void* in_mask, const void* out_mask,
+                              uint8_t* out) {
+    if (!votes || !out) return fail(RAFTHIP_EINVAL, "votes/out is NULL");
+    rafthip_engine* e = nullptr;
+    int rc = oneshot_engine(device, num_groups, num_slots, in_mask, out_mask, &e);
+    if (rc) return rc;
+    rc = rafthip_upload_votes(e, 0, num_groups, votes, num_groups);
+    if (!rc) rc = rafthip_tally_votes(e);
+    if (!rc) rc = rafthip_read_vote_result(e, 0, num_groups, out, nullptr, nullptr);
+    char keep[sizeof(g_err)];
+    memcpy(keep, g_err, sizeof(keep));
+    rafthip_destroy(e);
+    memcpy(g_err, keep, sizeof(keep));
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,367 @@
+"""GPU parity: the HIP engine, called through the C ABI, against the CPU oracle
+and the reference's golden vectors.  Bit-exact: the path is uint64/uint8 only."""
+import numpy as np
+import pytest
+
+import golden_util as gu
+import raft_amd
+
+pytestmark = pytest.mark.gpu
+
+CASES = gu.load_cases()
+TABLES = gu.load_tables()
+
+
+def rand_masks(rng, S, G, joint_frac=0.5, empty_frac=0.02):
+    mdt = gu.mask_dtype(S)
+    full = (1 << S) - 1
+
+    def rnd():
+        if S < 64:
+            return rng.integers(0, full + 1, size=G, dtype=np.uint64)
+        return rng.integers(0, 1 << 63, size=G, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=G, dtype=np.uint64)
+
+    m0 = rnd()
+    m1 = np.where(rng.random(G) < joint_frac, rnd(), np.uint64(0))
+    m0 = np.where(rng.random(G) < empty_frac, np.uint64(0), m0)
+    return m0.astype(mdt), m1.astype(mdt)
+
+
+def rand_match(rng, S, G):
+    """Mixture: full-range u64 (incl. >= 2^63), small values with many ties, zeros."""
+    a = rng.integers(0, 1 << 63, size=(S, G), dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=(S, G), dtype=np.uint64)
+    b = rng.integers(0, 8, size=(S, G), dtype=np.uint64)
+    sel = rng.random((S, G))
+    m = np.where(sel < 0.4, a, b)
+    m = np.where(sel > 0.9, np.uint64(0), m)
+    return np.ascontiguousarray(m.astype(np.uint64))
+
+
+# ---------------------------------------------------------------------------
+# golden vectors through the engine
+# ---------------------------------------------------------------------------
+
+@pytest.mark.parametrize("nslots", [None, 8, 12, 16, 24, 32, 40, 64])
+@pytest.mark.parametrize("swap", [False, True])
+def test_golden_committed(oracle, nslots, swap):
+    plane, m0, m1, exp = gu.cases_to_planes(CASES, "committed", nslots=nslots, swap=swap)
+    S, G = plane.shape
+    with raft_amd.Engine(G, S) as e:
+        e.upload_config(m0, m1)
+        e.upload_match(plane)
+        e.commit()
+        got = e.read_commit()
+    assert np.array_equal(got, exp)
+
+
+@pytest.mark.parametrize("nslots", [None, 8, 12, 32, 64])
+@pytest.mark.parametrize("swap", [False, True])
+def test_golden_votes(oracle, nslots, swap):
+    votes, m0, m1, exp = gu.cases_to_planes(CASES, "vote", nslots=nslots, swap=swap)
+    S, G = votes.shape
+    with raft_amd.Engine(G, S) as e:
+        e.upload_config(m0, m1)
+        e.upload_votes(votes)
+        e.tally_votes()
+        res, gr, rj = e.read_vote_result()
+    assert np.array_equal(res, exp)
+    ores, ogr, orj = oracle.batch_tally_votes(votes, m0, m1)
+    assert np.array_equal(gr, ogr) and np.array_equal(rj, orj)
+
+
+def test_golden_oneshot_entry_points():
+    plane, m0, m1, exp = gu.cases_to_planes(CASES, "committed")
+    assert np.array_equal(raft_amd.batch_committed_index(plane, m0, m1), exp)
+    votes, v0, v1, vexp = gu.cases_to_planes(CASES, "vote")
+    assert np.array_equal(raft_amd.batch_vote_result(votes, v0, v1), vexp)
+    # non-joint form: out_mask omitted == zero MajorityConfig (datadriven_test.go:179)
+    nj = [c for c in CASES if not c["joint"]]
+    plane, m0, m1, exp = gu.cases_to_planes(nj, "committed")
+    assert np.array_equal(raft_amd.batch_committed_index(plane, m0, None), exp)
+
+
+def test_testcommit_and_paper_tables(oracle):
+    for row in TABLES["TestCommit"]["rows"]:
+        n = len(row["matches"])
+        plane = np.array(row["matches"], dtype=np.uint64).reshape(n, 1)
+        with raft_amd.Engine(1, n) as e:
+            e.set_uniform_config(n)
+            e.upload_match(plane)
+            e.commit()
+            mci = int(e.read_commit()[0])
+        terms = {i: t for i, t in row["logs"]}
+        assert oracle.log_maybe_commit(0, mci, terms.get(mci, 0), row["smTerm"]) == row["w"], row
+    li = 1
+    for row in TABLES["TestLeaderAcknowledgeCommit"]["rows"]:
+        n = row["size"]
+        with raft_amd.Engine(1, n) as e:
+            e.set_uniform_config(n)
+            recs = np.zeros(1 + len(row["acceptors"]), dtype=raft_amd.ACK_DTYPE)
+            e.upload_match(np.full((n, 1), li, dtype=np.uint64))
+            recs["slot"] = [0] + [a - 1 for a in row["acceptors"]]
+            recs["index"] = li + 1
+            e.scatter_acks(recs)
+            e.commit()
+            assert (int(e.read_commit()[0]) > li) == row["wack"], row
+
+
+def test_progress_update_table():
+    t = TABLES["TestProgressUpdate"]
+    for row in t["rows"]:
+        with raft_amd.Engine(1, 1) as e:
+            e.upload_match(np.array([[t["prevM"]]], dtype=np.uint64))
+            recs = np.zeros(1, dtype=raft_amd.ACK_DTYPE)
+            recs["index"] = row["update"]
+            e.scatter_acks(recs)
+            assert int(e.read_match()[0, 0]) == row["wm"]
+
+
+# ---------------------------------------------------------------------------
+# randomised differential tests against the oracle
+# ---------------------------------------------------------------------------
+
+@pytest.mark.parametrize("V", [1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("G", [1, 511, 4097])
+def test_commit_uniform(oracle, V, G):
+    rng = np.random.default_rng(100 + V)
+    S = min(8, V + 1)  # one learner row when it fits
+    match = rand_match(rng, S, G)
+    with raft_amd.Engine(G, S) as e:
+        e.set_uniform_config(V)
+        e.upload_match(match)
+        e.commit()
+        got = e.read_commit()
+    assert np.array_equal(got, oracle.batch_committed(match, uniform_voters=V))
+
+
+@pytest.mark.parametrize("S", list(range(1, 9)))
+def test_commit_masked_small(oracle, S):
+    rng = np.random.default_rng(200 + S)
+    G = 20011
+    match = rand_match(rng, S, G)
+    m0, m1 = rand_masks(rng, S, G)
+    with raft_amd.Engine(G, S) as e:
+        e.upload_config(m0, m1)
+        e.upload_match(match)
+        e.commit()
+        got = e.read_commit()
+    assert np.array_equal(got, oracle.batch_committed(match, m0, m1))
+
+
+@pytest.mark.parametrize("S", [9, 11, 16, 17, 25, 32, 33, 48, 63, 64])
+def test_commit_wide(oracle, S):
+    rng = np.random.default_rng(300 + S)
+    G = 3001
+    match = rand_match(rng, S, G)
+    m0, m1 = rand_masks(rng, S, G)
+    with raft_amd.Engine(G, S) as e:
+        e.upload_config(m0, m1)
+        e.upload_match(match)
+        e.commit()
+        got = e.read_commit()
+        assert np.array_equal(got, oracle.batch_committed(match, m0, m1))
+        # uniform config on the wide path
+        V = S - 1
+        e.set_uniform_config(V)
+        e.commit()
+        assert np.array_equal(e.read_commit(), oracle.batch_committed(match, uniform_voters=V))
+
+
+def test_commit_wide_non_joint_wave(oracle):
+    """All-non-joint wavefronts take the skip-outgoing branch."""
+    rng = np.random.default_rng(5)
+    S, G = 20, 1000
+    match = rand_match(rng, S, G)
+    m0, _ = rand_masks(rng, S, G)
+    m1 = np.zeros_like(m0)
+    with raft_amd.Engine(G, S) as e:
+        e.upload_config(m0, m1)
+        e.upload_match(match)
+        e.commit()
+        assert np.array_equal(e.read_commit(), oracle.batch_committed(match, m0, m1))
+
+
+def test_empty_config_commits_infinity():
+    with raft_amd.Engine(100, 3) as e:  # fresh engine: both halves empty
+        e.commit()
+        assert (e.read_commit() == np.uint64(gu.U64MAX)).all()
+    with raft_amd.Engine(100, 20) as e:
+        e.commit()
+        assert (e.read_commit() == np.uint64(gu.U64MAX)).all()
+
+
+@pytest.mark.parametrize("S", [3, 5, 8, 12, 40, 64])
+def test_tallies_random(oracle, S):
+    rng = np.random.default_rng(400 + S)
+    G = 50021 if S <= 8 else 5003
+    mdt = gu.mask_dtype(S)
+    m0, m1 = rand_masks(rng, S, G)
+    votes = rng.choice(np.array([0, 1, 2], dtype=np.uint8), size=(S, G), p=[0.4, 0.2, 0.4])
+    votes = np.ascontiguousarray(votes)
+    learners = (~(m0 | m1)) & mdt((1 << S) - 1 if S < 64 else gu.U64MAX)
+    bits_a, _ = rand_masks(rng, S, G, joint_frac=0, empty_frac=0)
+    bits_k, _ = rand_masks(rng, S, G, joint_frac=0, empty_frac=0.3)
+    with raft_amd.Engine(G, S) as e:
+        e.upload_config(m0, m1, learners)
+        e.upload_votes(votes)
+        e.tally_votes()
+        res, gr, rj = e.read_vote_result()
+        ores, ogr, orj = oracle.batch_tally_votes(votes, m0, m1, learners)
+        assert np.array_equal(res, ores)
+        assert np.array_equal(gr, ogr) and np.array_equal(rj, orj)
+        e.upload_active(bits_a)
+        e.quorum_active()
+        assert np.array_equal(e.read_quorum_active(), oracle.batch_quorum_active(bits_a, S, m0, m1, learners))
+        e.upload_acks(bits_k)
+        e.ack_quorum()
+        assert np.array_equal(e.read_ack_quorum(), oracle.batch_ack_quorum(bits_k, S, m0, m1))
+        # uniform config
+        V = max(1, S - 2)
+        e.set_uniform_config(V)
+        e.tally_votes()
+        res, gr, rj = e.read_vote_result()
+        ores, ogr, orj = oracle.batch_tally_votes(votes, uniform_voters=V)
+        assert np.array_equal(res, ores) and np.array_equal(gr, ogr) and np.array_equal(rj, orj)
+        e.quorum_active()
+        assert np.array_equal(e.read_quorum_active(), oracle.batch_quorum_active(bits_a, S, uniform_voters=V))
+        e.ack_quorum()
+        assert np.array_equal(e.read_ack_quorum(), oracle.batch_ack_quorum(bits_k, S, uniform_voters=V))
+
+
+def test_check_quorum_three_voters(oracle):
+    """TestLeaderStepdownWhenQuorumActive/Lost, raft_test.go:1911-1944."""
+    with raft_amd.Engine(4, 3) as e:
+        e.set_uniform_config(3)
+        e.upload_active(np.array([0b001, 0b011, 0b101, 0b111], dtype=np.uint8))
+        e.quorum_active()
+        assert e.read_quorum_active().tolist() == [0, 1, 1, 1]
+
+
+@pytest.mark.parametrize("S,G", [(9, 4001), (3, 70001), (20, 999)])
+def test_scatter_then_commit(oracle, S, G):
+    """cfg5 shape: ack stream (stale + duplicate cells) -> atomicMax -> commit pass."""
+    rng = np.random.default_rng(500 + S)
+    match = rng.integers(0, 1 << 40, size=(S, G), dtype=np.uint64)
+    N = 4 * G
+    recs = np.zeros(N, dtype=raft_amd.ACK_DTYPE)
+    recs["group"] = rng.integers(0, G, size=N)
+    recs["slot"] = rng.integers(0, S, size=N)
+    old = match[recs["slot"], recs["group"]]
+    recs["index"] = old + rng.integers(0, 64, size=N).astype(np.uint64)
+    stale = rng.random(N) < 0.05
+    recs["index"][stale] = old[stale] // np.uint64(2)
+    # a few malformed records must be dropped and counted, not faulted on
+    recs["group"][:3] = [G, G + 5, 0xFFFFFFFF]
+    recs["slot"][3:5] = [S, 255]
+    want = match.copy()
+    skipped = oracle.scatter_acks(want, recs)
+    V = min(S, 7)
+    with raft_amd.Engine(G, S) as e:
+        e.set_uniform_config(V)
+        e.upload_match(match)
+        e.scatter_acks(recs)
+        e.commit()
+        assert np.array_equal(e.read_match(), want)
+        assert np.array_equal(e.read_commit(), oracle.batch_committed(want, uniform_voters=V))
+        st = e.stats()
+        assert st["acks_rejected"] == skipped == 5
+        assert st["acks_applied"] == N
+
+
+@pytest.mark.parametrize("S,uniform", [(5, True), (6, False), (12, False)])
+def test_commit_changed_pairs(oracle, S, uniform):
+    rng = np.random.default_rng(600 + S)
+    G = 30011
+    match = rng.integers(1, 1 << 30, size=(S, G), dtype=np.uint64)
+    m0, m1 = rand_masks(rng, S, G, empty_frac=0)
+    with raft_amd.Engine(G, S) as e:
+        if uniform:
+            e.set_uniform_config(S)
+            kw = dict(uniform_voters=S)
+        else:
+            e.upload_config(m0, m1)
+            kw = dict(in_mask=m0, out_mask=m1)
+        e.upload_match(match)
+        want0 = oracle.batch_committed(match, **kw)
+        pairs, n = e.commit_changed()
+        nz = np.flatnonzero(want0 != 0)
+        assert n == len(nz)
+        assert np.array_equal(pairs["group"], nz.astype(np.uint64))  # sorted by group
+        assert np.array_equal(pairs["commit"], want0[nz])
+        # nothing changes on a second pass
+        pairs, n = e.commit_changed()
+        assert n == 0
+        # advance ~1% of the cells; only affected groups are reported
+        match2 = match.copy()
+        bump = rng.random((S, G)) < 0.01
+        match2[bump] += np.uint64(1000)
+        e.upload_match(match2)
+        want1 = oracle.batch_committed(match2, **kw)
+        pairs, n = e.commit_changed(max_pairs=10)
+        ch = np.flatnonzero(want1 != want0)
+        assert n == len(ch)
+        assert np.array_equal(pairs["group"], ch[:10].astype(np.uint64))
+        assert np.array_equal(e.read_commit(), want1)
+
+
+def test_partial_uploads_and_ranges(oracle):
+    rng = np.random.default_rng(9)
+    S, G = 5, 10000
+    match = rand_match(rng, S, G)
+    with raft_amd.Engine(G, S) as e:
+        e.set_uniform_config(3)
+        e.upload_match(match)
+        # conf change on groups [100, 200): materialises the uniform config for the rest
+        m0 = np.full(100, 0b11111, dtype=np.uint8)
+        m1 = np.full(100, 0b00111, dtype=np.uint8)
+        e.upload_config(m0, m1, first=100, count=100)
+        fm0 = np.full(G, 0b00111, dtype=np.uint8)
+        fm1 = np.zeros(G, dtype=np.uint8)
+        fm0[100:200], fm1[100:200] = m0, m1
+        e.commit()
+        assert np.array_equal(e.read_commit(), oracle.batch_committed(match, fm0, fm1))
+        # role change on groups [5000, 5100): Match resets to 0 (raft.go:774-784)
+        e.reset_match(5000, 100)
+        match[:, 5000:5100] = 0
+        e.commit()
+        assert np.array_equal(e.read_commit(5000, 100), oracle.batch_committed(match, fm0, fm1)[5000:5100])
+        with pytest.raises(raft_amd.RafthipError) as ei:
+            e.read_commit(G - 1, 2)
+        assert ei.value.code == -34
+
+
+def test_full_size_properties(oracle):
+    """BASELINE sizes (2^20 x 5, dist A and B): properties that need no full oracle pass —
+    joint-with-self and joint-with-empty equal the majority result, halves swap
+    symmetrically (datadriven_test.go:179-183,219), raising Match never lowers
+    the commit index, and a strided sample matches the oracle exactly."""
+    G, S = 1 << 20, 5
+    for name, match in (("A", gu.dist_a(0x5EED0002, S, G)), ("B", gu.dist_b(0x5EED0002, S, G))):
+        with raft_amd.Engine(G, S) as e:
+            e.set_uniform_config(S)
+            e.upload_match(match)
+            e.commit()
+            base = e.read_commit()
+            full = np.full(G, 0b11111, dtype=np.uint8)
+            zero = np.zeros(G, dtype=np.uint8)
+            for a, b in ((full, zero), (full, full), (zero, full)):
+                e.upload_config(a, b)
+                e.commit()
+                assert np.array_equal(e.read_commit(), base), name
+            # exact check on a sample
+            idx = np.arange(0, G, 257)
+            sample = np.ascontiguousarray(match[:, idx])
+            assert np.array_equal(base[idx], oracle.batch_committed(sample, uniform_voters=S))
+            # median-of-5 bounds: 3 values >= result and 3 values <= result
+            assert ((match >= base).sum(axis=0) >= 3).all() and ((match <= base).sum(axis=0) >= 3).all()
+            # monotone: acks only raise Match, so the commit index cannot drop
+            rng = np.random.default_rng(3)
+            N = 1 << 20
+            recs = np.zeros(N, dtype=raft_amd.ACK_DTYPE)
+            recs["group"] = rng.integers(0, G, size=N)
+            recs["slot"] = rng.integers(0, S, size=N)
+            recs["index"] = rng.integers(0, 1 << 62, size=N)
+            e.set_uniform_config(S)
+            e.scatter_acks(recs)
+            e.commit()
+            assert (e.read_commit() >= base).all(), name
