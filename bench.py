@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the batched quorum engine.
+
+Metric (BASELINE.json): quorum evals/sec (groups/s) at 1M x 5 voters.
+
+A "step" is one ProgressTracker.Committed pass (K1, k_commit_uniform<5>) over
+one batch of 2^20 Raft groups x 5 voters, non-joint, dist A
+(quorum/bench_test.go:30-33), with Match planes already resident in HBM.  One
+batch is 40 MiB in + 8 MiB out — smaller than the 256 MiB Infinity Cache — so
+the steps rotate over --batches distinct resident batches (default 12, 576 MiB)
+to make every pass read cold HBM instead of re-reading a cached batch.
+
+N > 1: one process per GPU (torch.distributed / RCCL for the barrier and the
+max-over-ranks); groups shard by group-id range, every rank runs the same
+steps on its own shard (weak scaling, no data-path collective).  The one
+exchange step of the design — the all-gather of changed (group, commit) pairs
+— is timed separately after the main loop and reported under "extra".
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+G_BATCH = 1 << 20
+VOTERS = 5
+BYTES_PER_GROUP = VOTERS * 8 + 8  # 5 Match loads + 1 commit store
+HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def splitmix_batch(seed, S, G):
+    import golden_util as gu
+    return gu.dist_a(seed, S, G)
+
+
+def cpu_baseline(match, seconds=2.0):
+    """The oracle's reference-shaped loop (per-group id set + id-keyed map,
+    CommittedIndex per group) on the host cores.  A baseline, not the product."""
+    import oracle
+    threads = min(16, os.cpu_count() or 1)
+    cb = oracle.CpuBaseline(match, VOTERS)
+    used = cb.run(threads)  # warm-up pass
+    n, t0 = 0, time.perf_counter()
+    while True:
+        cb.run(threads)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds:
+            break
+    ref = cb.out.copy()
+    cb.close()
+    return {
+        "value": n * match.shape[1] / dt, "unit": "groups/s", "cores": int(used), "kind": "port",
+        "sample": "%d passes over one 2^20-group x 5-voter dist-A batch (%.1f s wall, %d OpenMP threads), "
+                  "oracle/quorum_oracle.c map-shaped CommittedIndex loop" % (n, dt, used),
+    }, ref
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--batches", type=int, default=12, help="distinct resident batches to rotate over")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import raft_amd
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the engine has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    stream = torch.cuda.Stream(device=dev)
+    engines = []
+    first_match = None
+    for b in range(args.batches):
+        # group-id range of this rank's shard of batch b: seeds differ per (rank, batch)
+        m = splitmix_batch(0x5EED0000 + 1000 * rank + b, VOTERS, G_BATCH)
+        e = raft_amd.Engine(G_BATCH, VOTERS, device=local_rank, stream=stream.cuda_stream)
+        e.set_uniform_config(VOTERS)
+        e.upload_match(m)
+        engines.append(e)
+        if b == 0:
+            first_match = m
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def run(n):
+        nb = len(engines)
+        for i in range(n):
+            engines[i % nb].commit()
+
+    with torch.cuda.stream(stream):
+        run(args.warmup)
+        barrier()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record(stream)
+        run(args.steps)
+        ev1.record(stream)
+        barrier()
+        t1 = time.perf_counter()
+    wall = t1 - t0
+    gpu_ms = ev0.elapsed_time(ev1)
+
+    if world > 1:
+        t = torch.tensor([wall, gpu_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall, gpu_ms = float(t[0]), float(t[1])
+
+    # correctness spot check of what was timed (oracle = checker only)
+    import oracle
+    got = engines[0].read_commit()
+    idx = np.arange(0, G_BATCH, 4099)
+    want = oracle.batch_committed(np.ascontiguousarray(first_match[:, idx]), uniform_voters=VOTERS)
+    if not np.array_equal(got[idx], want):
+        raise SystemExit("bench: GPU result differs from the oracle")
+
+    extra = {}
+    # single-launch latency (launch + kernel + sync), the floor a host sees at G = 2^20
+    with torch.cuda.stream(stream):
+        lat = []
+        for i in range(50):
+            torch.cuda.synchronize()
+            a = time.perf_counter()
+            engines[i % len(engines)].commit()
+            torch.cuda.synchronize()
+            lat.append(time.perf_counter() - a)
+    extra["single_launch_sync_us"] = round(1e6 * float(np.median(lat)), 2)
+
+    # the one exchange step: changed (group, commit) pairs -> every rank
+    from raft_amd import multigpu
+    with torch.cuda.stream(stream):
+        e0 = engines[0]
+        recs = np.zeros(G_BATCH // 8, dtype=raft_amd.ACK_DTYPE)  # acks touching 1/8 of the groups
+        rng = np.random.default_rng(rank)
+        recs["group"] = rng.integers(0, G_BATCH, size=len(recs))
+        recs["slot"] = rng.integers(0, VOTERS, size=len(recs))
+        recs["index"] = np.uint64(1) << np.uint64(63)
+        e0.scatter_acks(recs)
+        torch.cuda.synchronize()
+        a = time.perf_counter()
+        pairs, n_changed = e0.commit_changed()
+        b = time.perf_counter()
+        allp = multigpu.allgather_changed(pairs, rank * G_BATCH, dev if world > 1 else None)
+        torch.cuda.synchronize()
+        c = time.perf_counter()
+    extra["commit_changed_ms"] = round(1e3 * (b - a), 3)
+    extra["changed_pairs_rank0"] = int(n_changed)
+    extra["allgather_changed_ms"] = round(1e3 * (c - b), 3)
+    extra["allgather_pairs_total"] = int(len(allp))
+
+    if rank == 0:
+        total_groups = world * args.steps * G_BATCH
+        kernel_s = gpu_ms * 1e-3 / args.steps  # average launch duration over the timed region
+        achieved = BYTES_PER_GROUP * G_BATCH / kernel_s / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_commit_uniform5.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "quorum evals/sec (groups/s) at 1M x 5 voters",
+            "value": total_groups / wall,
+            "unit": "groups/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * wall / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u64",
+            "data": "synthetic",
+            "config": {
+                "workload": "ProgressTracker.Committed, 2^20 groups x 5 voters per GPU per step, non-joint, "
+                            "dist A (bench_test.go:30-33), rotating over %d HBM-resident batches" % args.batches,
+                "groups_per_step_per_gpu": G_BATCH, "voters": VOTERS, "batches": args.batches,
+                "sharding": "group-id range, no data-path collective",
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "kernel": "k_commit_uniform<5,2,false>", "bytes_per_group": BYTES_PER_GROUP,
+                "avg_launch_us": kernel_s * 1e6,
+            },
+            "extra": extra,
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"], _ = cpu_baseline(first_match)
+        print(json.dumps(out), flush=True)
+
+    for e in engines:
+        e.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

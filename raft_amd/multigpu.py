@@ -1,0 +1,75 @@
+"""Multi-GPU plumbing: one process per GPU, groups sharded by contiguous
+group-id range (groups are independent — no term of quorum/majority.go or
+tracker/tracker.go couples two groups), and the path's ONE exchange step: an
+all-gather of the changed (group, commit) pairs so that every rank (and the
+host loop that feeds raft.maybeCommit, raft.go:755-758) sees the full set.
+
+Backend: torch.distributed — "nccl" (= RCCL over xGMI) on GPUs, "gloo" in the
+CPU tests.  Two collectives per exchange: the per-rank counts, then one padded
+payload all-gather sized by the largest count.
+"""
+import numpy as np
+
+from .capi import PAIR_DTYPE
+
+
+def shard_range(total_groups, rank, world):
+    """Contiguous group-id range [first, first+count) owned by `rank`."""
+    base, rem = divmod(total_groups, world)
+    first = rank * base + min(rank, rem)
+    return first, base + (1 if rank < rem else 0)
+
+
+def owner_of(group, total_groups, world):
+    """Rank that owns a global group id (inverse of shard_range)."""
+    base, rem = divmod(total_groups, world)
+    cut = rem * (base + 1)
+    if group < cut:
+        return group // (base + 1)
+    return rem + (group - cut) // base
+
+
+def route_acks(recs, total_groups, world):
+    """Split global-id ack records into per-rank arrays with shard-local ids."""
+    base, rem = divmod(total_groups, world)
+    g = recs["group"].astype(np.int64)
+    cut = rem * (base + 1)
+    owner = np.where(g < cut, g // (base + 1), rem + (g - cut) // max(base, 1))
+    out = []
+    for r in range(world):
+        first, _ = shard_range(total_groups, r, world)
+        sel = recs[owner == r].copy()
+        sel["group"] -= np.uint32(first)
+        out.append(sel)
+    return out
+
+
+def allgather_changed(pairs, group_base=0, device=None, group=None):
+    """All-gather changed pairs across ranks.
+
+    pairs: numpy PAIR_DTYPE with shard-local group ids; group_base: first global
+    group id of this rank's shard.  Returns the concatenation over ranks (global
+    ids, rank order — hence sorted by group) as numpy PAIR_DTYPE.  Without an
+    initialised process group this is the local set, rebased.
+    """
+    import torch
+    import torch.distributed as dist
+
+    local = np.ascontiguousarray(pairs, dtype=PAIR_DTYPE).copy()
+    local["group"] += np.uint64(group_base)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return local
+    world = dist.get_world_size(group)
+    dev = device if device is not None else torch.device("cpu")
+    n = torch.tensor([len(local)], dtype=torch.int64, device=dev)
+    counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(counts, n, group=group)
+    counts = [int(c.item()) for c in counts]
+    width = max(max(counts), 1)
+    buf = torch.zeros(width * 2, dtype=torch.int64, device=dev)
+    if len(local):
+        buf[: 2 * len(local)] = torch.from_numpy(local.view(np.int64).reshape(-1).copy()).to(dev)
+    outs = [torch.empty(width * 2, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(outs, buf, group=group)
+    parts = [o[: 2 * c].cpu().numpy().view(PAIR_DTYPE) for o, c in zip(outs, counts)]
+    return np.concatenate(parts) if parts else local[:0]

@@ -1,0 +1,95 @@
+"""World-size-2 gloo tests of the sharding plumbing and the changed-pair
+all-gather (runs on CPU; the per-rank compute is covered by the GPU tests)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+from raft_amd import multigpu
+from raft_amd.capi import ACK_DTYPE, PAIR_DTYPE
+
+
+def test_shard_ranges_cover_everything():
+    for total in (1, 7, 8, 1 << 20, (1 << 24) + 3):
+        for world in (1, 2, 3, 8):
+            nxt = 0
+            for r in range(world):
+                first, count = multigpu.shard_range(total, r, world)
+                assert first == nxt
+                nxt += count
+                if count:
+                    assert multigpu.owner_of(first, total, world) == r
+                    assert multigpu.owner_of(first + count - 1, total, world) == r
+            assert nxt == total
+
+
+def test_route_acks():
+    rng = np.random.default_rng(0)
+    total, world = 1003, 4
+    recs = np.zeros(5000, dtype=ACK_DTYPE)
+    recs["group"] = rng.integers(0, total, size=len(recs))
+    recs["slot"] = rng.integers(0, 5, size=len(recs))
+    recs["index"] = rng.integers(0, 1 << 40, size=len(recs))
+    parts = multigpu.route_acks(recs, total, world)
+    assert sum(len(p) for p in parts) == len(recs)
+    for r, p in enumerate(parts):
+        first, count = multigpu.shard_range(total, r, world)
+        assert (p["group"] < count).all()
+        back = p.copy()
+        back["group"] += np.uint32(first)
+        sel = recs[(recs["group"] >= first) & (recs["group"] < first + count)]
+        assert np.array_equal(np.sort(back, order=["group", "slot", "index"]),
+                              np.sort(sel, order=["group", "slot", "index"]))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, total, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    first, count = multigpu.shard_range(total, rank, world)
+    rng = np.random.default_rng(100 + rank)
+    # rank 1 reports nothing in round 0 (ragged / empty payloads)
+    for rnd in range(2):
+        n = 0 if (rank == 1 and rnd == 0) else int(rng.integers(1, count))
+        local_groups = np.sort(rng.choice(count, size=n, replace=False))
+        pairs = np.zeros(n, dtype=PAIR_DTYPE)
+        pairs["group"] = local_groups
+        pairs["commit"] = (local_groups + first) * 3 + rnd  # a function of the GLOBAL id
+        allp = multigpu.allgather_changed(pairs, first)
+        q.put((rank, rnd, n, allp.tobytes()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_allgather_changed_gloo_world2():
+    world, total = 2, 1001
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=100) for _ in range(world * 2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rnd in range(2):
+        views = {r: np.frombuffer(b, dtype=PAIR_DTYPE) for r, rr, n, b in got if rr == rnd}
+        ns = {r: n for r, rr, n, b in got if rr == rnd}
+        assert np.array_equal(views[0], views[1])  # every rank sees the same set
+        allp = views[0]
+        assert len(allp) == sum(ns.values())
+        assert (np.diff(allp["group"].astype(np.int64)) > 0).all()  # global ids, sorted
+        assert np.array_equal(allp["commit"], allp["group"] * 3 + rnd)
