@@ -140,7 +140,6 @@ int copy_rows(rafthip_engine* e, void* dst, u64 dst_stride_b, const void* src, u
 
 // ---- kernel dispatch -----------------------------------------------------
 
-constexpr int kGPT = 2;  // groups per lane in K1/K2: one 16-byte access per plane
 
 template <bool CHANGED>
 int launch_commit(rafthip_engine* e, u32* block_groups) {
@@ -154,14 +153,14 @@ int launch_commit(rafthip_engine* e, u32* block_groups) {
     }
     const bool uni = e->uniform && e->uniform_voters > 0;
     if (e->S <= 8) {
-        const u32 blocks = (u32)((G + (u64)kBlock * kGPT - 1) / ((u64)kBlock * kGPT));
-        *block_groups = kBlock * kGPT;
+        const u32 blocks = (u32)((G + kTileGroups - 1) / kTileGroups);
+        *block_groups = kTileGroups;
         if (CHANGED && blocks > e->counts_cap) return fail(RAFTHIP_EINVAL, "internal: counts capacity");
         if (uni) {
             switch (e->uniform_voters) {
 #define RAFTHIP_CASE_U(V)                                                                          \
     case V:                                                                                        \
-        hipLaunchKernelGGL((k_commit_uniform<V, kGPT, CHANGED>), dim3(blocks), dim3(kBlock), 0, st, \
+        hipLaunchKernelGGL((k_commit_uniform<V, CHANGED>), dim3(blocks), dim3(kCommitBlock), 0, st,   \
                            e->match, e->stride, G, e->commit, e->stage, e->counts);                \
         break;
                 RAFTHIP_CASE_U(1) RAFTHIP_CASE_U(2) RAFTHIP_CASE_U(3) RAFTHIP_CASE_U(4)
@@ -175,7 +174,7 @@ int launch_commit(rafthip_engine* e, u32* block_groups) {
             switch (e->S) {
 #define RAFTHIP_CASE_M(SS)                                                                         \
     case SS:                                                                                       \
-        hipLaunchKernelGGL((k_commit_masked<SS, kGPT, CHANGED>), dim3(blocks), dim3(kBlock), 0, st, \
+        hipLaunchKernelGGL((k_commit_masked<SS, CHANGED>), dim3(blocks), dim3(kCommitBlock), 0, st,   \
                            e->match, e->stride, G, m0, m1, e->commit, e->stage, e->counts);        \
         break;
                 RAFTHIP_CASE_M(1) RAFTHIP_CASE_M(2) RAFTHIP_CASE_M(3) RAFTHIP_CASE_M(4)
@@ -212,7 +211,7 @@ int launch_commit(rafthip_engine* e, u32* block_groups) {
 }
 
 int ensure_changed_buffers(rafthip_engine* e) {
-    const u32 bg = e->S <= 8 ? kBlock * kGPT : kBlock;
+    const u32 bg = e->S <= 8 ? kTileGroups : kBlock;
     const u32 blocks = (u32)((e->G + bg - 1) / bg);
     int rc;
     if ((rc = ensure(e, e->stage, (size_t)blocks * bg * sizeof(Pair), false))) return rc;

@@ -1,0 +1,162 @@
+// kbench.hip — in-process A/B of launch shapes for the commit kernel (K1).
+// Development tool, not part of the library: variants are timed interleaved in
+// one process (HIP events), over R rotating cold batches, so the numbers are
+// comparable.  Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iraft_amd/csrc
+//                     -o gpurun_out/kbench tools/kbench.hip
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+using namespace rafthip;
+
+#define CK(x)                                                                  \
+    do {                                                                       \
+        hipError_t e_ = (x);                                                   \
+        if (e_ != hipSuccess) {                                                \
+            fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_));            \
+            exit(1);                                                           \
+        }                                                                      \
+    } while (0)
+
+template <bool NT>
+__device__ __forceinline__ Vec<u64, 2> ld2(const u64* p) {
+    if constexpr (NT) {
+        Vec<u64, 2> r;
+        r.v[0] = __builtin_nontemporal_load(p);
+        r.v[1] = __builtin_nontemporal_load(p + 1);
+        return r;
+    } else {
+        return load_vec<u64, 2>(p);
+    }
+}
+template <bool NT>
+__device__ __forceinline__ void st2(u64* p, const Vec<u64, 2>& x) {
+    if constexpr (NT) {
+        __builtin_nontemporal_store(x.v[0], p);
+        __builtin_nontemporal_store(x.v[1], p + 1);
+    } else {
+        store_vec<u64, 2>(p, x);
+    }
+}
+
+// CH chunks of 2 groups per lane; chunk c of a block covers a contiguous run of
+// BLOCK*2 groups, so each wave instruction still reads 1 KiB contiguous.
+template <int V, int CH, int BLOCK, int NT, bool SUM>
+__global__ __launch_bounds__(BLOCK) void kv(const u64* __restrict__ match, u64 stride, u64 G,
+                                            u64* __restrict__ commit, u64 tiles) {
+    for (u64 tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const u64 base = tile * (u64)(BLOCK * 2 * CH) + threadIdx.x * 2;
+        Vec<u64, 2> in[CH][V];
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+#pragma unroll
+            for (int s = 0; s < V; ++s) in[c][s] = ld2<(NT == 1 || NT == 2)>(match + (u64)s * stride + base + (u64)c * BLOCK * 2);
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            Vec<u64, 2> res;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                u64 a[V];
+#pragma unroll
+                for (int s = 0; s < V; ++s) a[s] = in[c][s].v[j];
+                if constexpr (SUM) {
+                    u64 t = 0;
+#pragma unroll
+                    for (int s = 0; s < V; ++s) t += a[s];
+                    res.v[j] = t;
+                } else {
+                    res.v[j] = committed_fixed<V>(a);
+                }
+            }
+            st2<(NT == 1 || NT == 3)>(commit + base + (u64)c * BLOCK * 2, res);
+        }
+    }
+}
+
+struct Variant {
+    std::string name;
+    void (*launch)(const u64*, u64, u64, u64*, hipStream_t);
+};
+
+template <int V, int CH, int BLOCK, int NT, bool SUM, int PERSIST /*blocks per CU, 0 = one tile per block*/>
+void launch_kv(const u64* m, u64 stride, u64 G, u64* c, hipStream_t st) {
+    constexpr u64 per = (u64)BLOCK * 2 * CH;
+    static_assert(4096 % per == 0, "tile must divide the plane stride granule, or the last tile runs off the plane");
+    const u64 tiles = (G + per - 1) / per;
+    u64 grid = tiles;
+    if (PERSIST > 0) grid = std::min<u64>(tiles, (u64)256 * PERSIST);
+    hipLaunchKernelGGL((kv<V, CH, BLOCK, NT, SUM>), dim3((unsigned)grid), dim3(BLOCK), 0, st, m, stride, G, c, tiles);
+}
+
+int main(int argc, char** argv) {
+    const u64 G = argc > 1 ? strtoull(argv[1], 0, 0) : (1ull << 20);
+    const int R = argc > 2 ? atoi(argv[2]) : 12;
+    const int rounds = argc > 3 ? atoi(argv[3]) : 7;
+    const int iters = argc > 4 ? atoi(argv[4]) : 240;
+    constexpr int V = 5;
+    const u64 stride = (G + 4095) / 4096 * 4096;
+    std::vector<u64*> match(R), commit(R);
+    std::vector<u64> host((size_t)V * stride);
+    u64 x = 0x5EED;
+    for (int r = 0; r < R; ++r) {
+        for (auto& h : host) {
+            x += 0x9E3779B97F4A7C15ull;
+            u64 z = x;
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+            z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+            h = (z ^ (z >> 31)) >> 1;
+        }
+        CK(hipMalloc(&match[r], host.size() * 8));
+        CK(hipMalloc(&commit[r], stride * 8));
+        CK(hipMemcpy(match[r], host.data(), host.size() * 8, hipMemcpyHostToDevice));
+    }
+    hipStream_t st;
+    CK(hipStreamCreate(&st));
+    std::vector<Variant> vs = {
+        {"ch2_b256", launch_kv<V, 2, 256, 0, false, 0>},
+        {"ch2_b256_nt", launch_kv<V, 2, 256, 1, false, 0>},
+        {"ch2_b256_ntL", launch_kv<V, 2, 256, 2, false, 0>},
+        {"ch2_b256_ntS", launch_kv<V, 2, 256, 3, false, 0>},
+        {"ch1_b256_nt", launch_kv<V, 1, 256, 1, false, 0>},
+        {"ch4_b256_nt", launch_kv<V, 4, 256, 1, false, 0>},
+        {"ch2_b64_nt", launch_kv<V, 2, 64, 1, false, 0>},
+        {"ch2_b128_nt", launch_kv<V, 2, 128, 1, false, 0>},
+        {"ch2_b512_nt", launch_kv<V, 2, 512, 1, false, 0>},
+        {"ch2_b1024_nt", launch_kv<V, 2, 1024, 1, false, 0>},
+        {"ch1_b1024_nt", launch_kv<V, 1, 1024, 1, false, 0>},
+        {"ch4_b64_nt", launch_kv<V, 4, 64, 1, false, 0>},
+        {"ch2_b512_nt_p2", launch_kv<V, 2, 512, 1, false, 2>},
+        {"SUM_ch2_b256_nt", launch_kv<V, 2, 256, 1, true, 0>},
+    };
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    std::vector<std::vector<float>> us(vs.size());
+    for (int rd = 0; rd < rounds; ++rd) {
+        for (size_t v = 0; v < vs.size(); ++v) {
+            for (int i = 0; i < 24; ++i) vs[v].launch(match[i % R], stride, G, commit[i % R], st);
+            CK(hipEventRecord(e0, st));
+            for (int i = 0; i < iters; ++i) vs[v].launch(match[i % R], stride, G, commit[i % R], st);
+            CK(hipEventRecord(e1, st));
+            CK(hipEventSynchronize(e1));
+            float ms;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            us[v].push_back(ms * 1e3f / iters);
+        }
+    }
+    CK(hipGetLastError());
+    printf("G=%llu R=%d rounds=%d iters=%d bytes/launch=%.1f MB\n", G, R, rounds, iters, G * 48 / 1e6);
+    for (size_t v = 0; v < vs.size(); ++v) {
+        std::sort(us[v].begin(), us[v].end());
+        const float med = us[v][us[v].size() / 2], mn = us[v][0];
+        printf("%-18s median %8.2f us  min %8.2f us  -> %7.1f GB/s (median)\n", vs[v].name.c_str(), med, mn,
+               G * 48.0 / med / 1e3);
+    }
+    return 0;
+}
