@@ -358,8 +358,12 @@ ORACLE_API void oracle_batch_tally_votes(uint64_t G, int nslots, const uint8_t *
                                          const void *out_mask, const void *learner_mask,
                                          int mask_bytes, int uniform_voters, uint8_t *result,
                                          uint8_t *granted, uint8_t *rejected) {
-    uint64_t ids0[64], ids1[64], vid[64], vval[64];
-    for (uint64_t g = 0; g < G; g++) {
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+    for (int64_t gi = 0; gi < (int64_t)G; gi++) {
+        const uint64_t g = (uint64_t)gi;
+        uint64_t ids0[64], ids1[64], vid[64], vval[64];
         uint64_t m0, m1, ml;
         if (in_mask) {
             m0 = load_mask(in_mask, mask_bytes, g);
@@ -402,8 +406,12 @@ ORACLE_API void oracle_batch_quorum_active(uint64_t G, int nslots, const void *a
                                            const void *in_mask, const void *out_mask,
                                            const void *learner_mask, int mask_bytes,
                                            int uniform_voters, uint8_t *out) {
-    uint64_t ids0[64], ids1[64], vid[64], vval[64];
-    for (uint64_t g = 0; g < G; g++) {
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+    for (int64_t gi = 0; gi < (int64_t)G; gi++) {
+        const uint64_t g = (uint64_t)gi;
+        uint64_t ids0[64], ids1[64], vid[64], vval[64];
         uint64_t m0, m1, ml;
         if (in_mask) {
             m0 = load_mask(in_mask, mask_bytes, g);
@@ -439,8 +447,12 @@ ORACLE_API void oracle_batch_quorum_active(uint64_t G, int nslots, const void *a
 ORACLE_API void oracle_batch_ack_quorum(uint64_t G, int nslots, const void *acks,
                                         const void *in_mask, const void *out_mask,
                                         int mask_bytes, int uniform_voters, uint8_t *out) {
-    uint64_t ids0[64], ids1[64], vid[64], vval[64];
-    for (uint64_t g = 0; g < G; g++) {
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+    for (int64_t gi = 0; gi < (int64_t)G; gi++) {
+        const uint64_t g = (uint64_t)gi;
+        uint64_t ids0[64], ids1[64], vid[64], vval[64];
         uint64_t m0, m1;
         if (in_mask) {
             m0 = load_mask(in_mask, mask_bytes, g);

@@ -1,0 +1,369 @@
+// tracker_batch.cpp — BatchProgressTracker: the id-keyed bookkeeping of
+// tracker.ProgressTracker (tracker/tracker.go:117-290) for many groups, above
+// one librafthip.so engine.  No quorum arithmetic happens here: this file owns
+// the id -> slot maps and host shadows of the small planes, and calls the GPU.
+#include "tracker_batch.hpp"
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+
+namespace raft {
+namespace tracker {
+
+int BatchProgressTracker::fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(err_, sizeof(err_), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int BatchProgressTracker::lib(int rc) {
+    if (rc) snprintf(err_, sizeof(err_), "%s", rafthip_last_error());
+    return rc;
+}
+
+int BatchProgressTracker::Make(int device, uint64_t groups, uint32_t max_slots, BatchProgressTracker** out) {
+    if (!out) return RAFTHIP_EINVAL;
+    *out = nullptr;
+    BatchProgressTracker* t = new (std::nothrow) BatchProgressTracker();
+    if (!t) return RAFTHIP_ENOMEM;
+    rafthip_config cfg;
+    memset(&cfg, 0, sizeof(cfg));
+    cfg.struct_size = sizeof(cfg);
+    cfg.device = device;
+    cfg.num_groups = groups;
+    cfg.num_slots = max_slots;
+    int rc = rafthip_create(&cfg, &t->e_);
+    if (rc) {
+        delete t;
+        return rc;  // text in rafthip_last_error()
+    }
+    t->G_ = groups;
+    t->S_ = max_slots;
+    t->mb_ = (uint32_t)rafthip_mask_bytes(t->e_);
+    t->ids_.assign(groups * max_slots, 0);
+    t->used_.assign(groups, 0);
+    t->in_.assign(groups * t->mb_, 0);
+    t->out_.assign(groups * t->mb_, 0);
+    t->learner_.assign(groups * t->mb_, 0);
+    t->votes_.assign((size_t)max_slots * groups, RAFTHIP_CELL_NONE);
+    t->active_.assign(groups * t->mb_, 0);
+    t->rdacks_.assign(groups * t->mb_, 0);
+    t->pairs_.resize(groups);
+    // the engine must see zeroed bit planes even if no bit is ever set
+    t->touch(t->active_dirty_, 0);
+    t->touch(t->active_dirty_, groups - 1);
+    t->touch(t->rdacks_dirty_, 0);
+    t->touch(t->rdacks_dirty_, groups - 1);
+    t->touch(t->votes_dirty_, 0);
+    t->touch(t->votes_dirty_, groups - 1);
+    *out = t;
+    return RAFTHIP_OK;
+}
+
+BatchProgressTracker::~BatchProgressTracker() {
+    if (e_) rafthip_destroy(e_);
+}
+
+uint64_t BatchProgressTracker::get_mask(const std::vector<uint8_t>& plane, uint64_t g) const {
+    uint64_t m = 0;
+    memcpy(&m, plane.data() + g * mb_, mb_);  // little-endian host
+    return m;
+}
+
+void BatchProgressTracker::put_mask(std::vector<uint8_t>& plane, uint64_t g, uint64_t m) {
+    memcpy(plane.data() + g * mb_, &m, mb_);
+}
+
+void BatchProgressTracker::touch(uint64_t (&range)[2], uint64_t g) {
+    if (range[0] > range[1]) {
+        range[0] = range[1] = g;
+    } else {
+        if (g < range[0]) range[0] = g;
+        if (g > range[1]) range[1] = g;
+    }
+}
+
+int BatchProgressTracker::slot_of(uint64_t group, uint64_t id) const {
+    const uint64_t used = used_[group];
+    const uint64_t* ids = ids_.data() + group * S_;
+    for (uint32_t s = 0; s < S_; ++s)
+        if (((used >> s) & 1ull) && ids[s] == id) return (int)s;
+    return -1;
+}
+
+int BatchProgressTracker::push_config(uint64_t group) {
+    return lib(rafthip_upload_config(e_, group, 1, in_.data() + group * mb_, out_.data() + group * mb_,
+                                     learner_.data() + group * mb_));
+}
+
+int BatchProgressTracker::SetConfig(uint64_t group, const quorum::MajorityConfig& incoming,
+                                    const quorum::MajorityConfig& outgoing,
+                                    const quorum::MajorityConfig& learners) {
+    if (group >= G_) return fail(RAFTHIP_ERANGE, "group %llu outside [0, %llu)", (unsigned long long)group,
+                                 (unsigned long long)G_);
+    quorum::MajorityConfig all = incoming;
+    all.insert(outgoing.begin(), outgoing.end());
+    for (uint64_t id : learners) {
+        // Learners and voters never intersect — confchange/confchange.go:305-316
+        if (all.count(id)) return fail(RAFTHIP_EINVAL, "id %llu is both a voter and a learner", (unsigned long long)id);
+    }
+    all.insert(learners.begin(), learners.end());
+    if (all.size() > S_)
+        return fail(RAFTHIP_EINVAL, "group %llu needs %zu Progress rows; the tracker was made with %u slots",
+                    (unsigned long long)group, all.size(), S_);
+    int rc = Flush();  // queued acks were addressed with the old id -> slot map
+    if (rc) return rc;
+
+    uint64_t* ids = ids_.data() + group * S_;
+    uint64_t used = used_[group];
+    uint64_t active = get_mask(active_, group), rdacks = get_mask(rdacks_, group);
+    std::vector<uint64_t> row;  // the group's Match cells, fetched only if a slot changes hands
+    bool row_dirty = false;
+    auto fetch_row = [&]() -> int {
+        if (!row.empty()) return RAFTHIP_OK;
+        row.assign(S_, 0);
+        return lib(rafthip_read_match(e_, group, 1, row.data(), 1));
+    };
+    // Progress of ids that left the config is deleted (confchange.go:233-247).
+    for (uint32_t s = 0; s < S_; ++s) {
+        if (!((used >> s) & 1ull) || all.count(ids[s])) continue;
+        if ((rc = fetch_row())) return rc;
+        row[s] = 0;
+        row_dirty = true;
+        uint8_t& cell = votes_[(size_t)s * G_ + group];
+        if (cell != RAFTHIP_CELL_NONE) {  // Votes is keyed by id and survives the conf change (tracker.go:122)
+            stray_votes_[group][ids[s]] = (cell == RAFTHIP_CELL_GRANT);
+            cell = RAFTHIP_CELL_NONE;
+            touch(votes_dirty_, group);
+        }
+        if ((rdacks >> s) & 1ull) stray_acks_[group].insert(ids[s]);  // acks are keyed by id too (read_only.go:29-37)
+        used &= ~(1ull << s);
+        active &= ~(1ull << s);
+        rdacks &= ~(1ull << s);
+        ids[s] = 0;
+    }
+    // New ids get a fresh Progress: Match 0, RecentActive true (confchange.go:257-270).
+    for (uint64_t id : all) {
+        bool have = false;
+        for (uint32_t s = 0; s < S_; ++s) have |= ((used >> s) & 1ull) && ids[s] == id;
+        if (have) continue;
+        uint32_t s = 0;
+        while ((used >> s) & 1ull) ++s;
+        ids[s] = id;
+        used |= 1ull << s;
+        active |= 1ull << s;
+        auto sv = stray_votes_.find(group);
+        if (sv != stray_votes_.end()) {
+            auto it = sv->second.find(id);
+            if (it != sv->second.end()) {
+                votes_[(size_t)s * G_ + group] = it->second ? RAFTHIP_CELL_GRANT : RAFTHIP_CELL_REJECT;
+                touch(votes_dirty_, group);
+                sv->second.erase(it);
+            }
+        }
+        auto sa = stray_acks_.find(group);
+        if (sa != stray_acks_.end() && sa->second.erase(id)) rdacks |= 1ull << s;
+    }
+    used_[group] = used;
+    uint64_t in = 0, out = 0, lrn = 0;
+    for (uint32_t s = 0; s < S_; ++s) {
+        if (!((used >> s) & 1ull)) continue;
+        if (incoming.count(ids[s])) in |= 1ull << s;
+        if (outgoing.count(ids[s])) out |= 1ull << s;
+        if (learners.count(ids[s])) lrn |= 1ull << s;
+    }
+    put_mask(in_, group, in);
+    put_mask(out_, group, out);
+    put_mask(learner_, group, lrn);
+    put_mask(active_, group, active);
+    put_mask(rdacks_, group, rdacks);
+    touch(active_dirty_, group);
+    touch(rdacks_dirty_, group);
+    if (row_dirty && (rc = lib(rafthip_upload_match(e_, group, 1, row.data(), 1)))) return rc;
+    return push_config(group);
+}
+
+int BatchProgressTracker::ResetProgress(uint64_t group) {
+    if (group >= G_) return fail(RAFTHIP_ERANGE, "group %llu outside [0, %llu)", (unsigned long long)group,
+                                 (unsigned long long)G_);
+    int rc = Flush();
+    if (rc) return rc;
+    if ((rc = lib(rafthip_reset_match(e_, group, 1)))) return rc;
+    put_mask(active_, group, 0);
+    touch(active_dirty_, group);
+    return ResetVotes(group);
+}
+
+bool BatchProgressTracker::MaybeUpdate(uint64_t group, uint64_t id, uint64_t n) {
+    if (group >= G_) return false;
+    const int s = slot_of(group, id);
+    if (s < 0) return false;
+    rafthip_ack a;
+    a.group = (uint32_t)group;
+    a.slot = (uint32_t)s;
+    a.index = n;
+    acks_.push_back(a);
+    return true;
+}
+
+int BatchProgressTracker::Flush() {
+    if (acks_.empty()) return RAFTHIP_OK;
+    int rc = lib(rafthip_scatter_acks(e_, acks_.data(), acks_.size()));
+    acks_.clear();
+    return rc;
+}
+
+int BatchProgressTracker::Committed(std::vector<CommitPair>* changed) {
+    int rc = Flush();
+    if (rc) return rc;
+    static_assert(sizeof(CommitPair) == sizeof(rafthip_commit_pair), "pair layout");
+    uint64_t n = 0;
+    rc = lib(rafthip_commit_changed(e_, reinterpret_cast<rafthip_commit_pair*>(pairs_.data()), pairs_.size(), &n));
+    if (rc) return rc;
+    if (changed) changed->assign(pairs_.begin(), pairs_.begin() + (n < pairs_.size() ? n : pairs_.size()));
+    return RAFTHIP_OK;
+}
+
+int BatchProgressTracker::CommittedOf(uint64_t group, uint64_t* commit) {
+    if (!commit) return fail(RAFTHIP_EINVAL, "commit is NULL");
+    return lib(rafthip_read_commit(e_, group, 1, commit));
+}
+
+int BatchProgressTracker::Match(uint64_t group, uint64_t id, uint64_t* match) {
+    if (!match) return fail(RAFTHIP_EINVAL, "match is NULL");
+    if (group >= G_) return fail(RAFTHIP_ERANGE, "group %llu outside [0, %llu)", (unsigned long long)group,
+                                 (unsigned long long)G_);
+    const int s = slot_of(group, id);
+    if (s < 0) return fail(RAFTHIP_EINVAL, "group %llu has no Progress for id %llu", (unsigned long long)group,
+                           (unsigned long long)id);
+    int rc = Flush();
+    if (rc) return rc;
+    std::vector<uint64_t> row(S_, 0);
+    if ((rc = lib(rafthip_read_match(e_, group, 1, row.data(), 1)))) return rc;
+    *match = row[s];
+    return RAFTHIP_OK;
+}
+
+int BatchProgressTracker::ResetVotes(uint64_t group) {
+    if (group >= G_) return fail(RAFTHIP_ERANGE, "group %llu outside [0, %llu)", (unsigned long long)group,
+                                 (unsigned long long)G_);
+    for (uint32_t s = 0; s < S_; ++s) votes_[(size_t)s * G_ + group] = RAFTHIP_CELL_NONE;
+    stray_votes_.erase(group);
+    touch(votes_dirty_, group);
+    return RAFTHIP_OK;
+}
+
+int BatchProgressTracker::RecordVote(uint64_t group, uint64_t id, bool v) {
+    if (group >= G_) return fail(RAFTHIP_ERANGE, "group %llu outside [0, %llu)", (unsigned long long)group,
+                                 (unsigned long long)G_);
+    const int s = slot_of(group, id);
+    if (s < 0) {
+        // recorded all the same (tracker.go:260-265); it counts only if the id
+        // later becomes a voter before the next ResetVotes
+        stray_votes_[group].emplace(id, v);
+        return RAFTHIP_OK;
+    }
+    uint8_t& cell = votes_[(size_t)s * G_ + group];
+    if (cell == RAFTHIP_CELL_NONE) {  // the first vote of an id sticks
+        cell = v ? RAFTHIP_CELL_GRANT : RAFTHIP_CELL_REJECT;
+        touch(votes_dirty_, group);
+    }
+    return RAFTHIP_OK;
+}
+
+int BatchProgressTracker::TallyVotes() {
+    if (votes_dirty_[0] <= votes_dirty_[1]) {
+        const uint64_t first = votes_dirty_[0], count = votes_dirty_[1] - votes_dirty_[0] + 1;
+        int rc = lib(rafthip_upload_votes(e_, first, count, votes_.data() + first, G_));
+        if (rc) return rc;
+        votes_dirty_[0] = 1;
+        votes_dirty_[1] = 0;
+    }
+    return lib(rafthip_tally_votes(e_));
+}
+
+int BatchProgressTracker::VoteResultOf(uint64_t group, int* granted, int* rejected, quorum::VoteResult* result) {
+    uint8_t r = 0, g = 0, j = 0;
+    int rc = lib(rafthip_read_vote_result(e_, group, 1, &r, &g, &j));
+    if (rc) return rc;
+    if (granted) *granted = g;
+    if (rejected) *rejected = j;
+    if (result) *result = (quorum::VoteResult)r;
+    return RAFTHIP_OK;
+}
+
+int BatchProgressTracker::SetRecentActive(uint64_t group, uint64_t id, bool active) {
+    if (group >= G_) return fail(RAFTHIP_ERANGE, "group %llu outside [0, %llu)", (unsigned long long)group,
+                                 (unsigned long long)G_);
+    const int s = slot_of(group, id);
+    if (s < 0) return fail(RAFTHIP_EINVAL, "group %llu has no Progress for id %llu", (unsigned long long)group,
+                           (unsigned long long)id);
+    uint64_t m = get_mask(active_, group);
+    m = active ? (m | (1ull << s)) : (m & ~(1ull << s));
+    put_mask(active_, group, m);
+    touch(active_dirty_, group);
+    return RAFTHIP_OK;
+}
+
+int BatchProgressTracker::QuorumActive(std::vector<uint8_t>* active) {
+    if (!active) return fail(RAFTHIP_EINVAL, "active is NULL");
+    if (active_dirty_[0] <= active_dirty_[1]) {
+        const uint64_t first = active_dirty_[0], count = active_dirty_[1] - active_dirty_[0] + 1;
+        int rc = lib(rafthip_upload_active(e_, first, count, active_.data() + first * mb_));
+        if (rc) return rc;
+        active_dirty_[0] = 1;
+        active_dirty_[1] = 0;
+    }
+    int rc = lib(rafthip_quorum_active(e_));
+    if (rc) return rc;
+    active->assign(G_, 0);
+    return lib(rafthip_read_quorum_active(e_, 0, G_, active->data()));
+}
+
+int BatchProgressTracker::RecvAck(uint64_t group, uint64_t id) {
+    if (group >= G_) return fail(RAFTHIP_ERANGE, "group %llu outside [0, %llu)", (unsigned long long)group,
+                                 (unsigned long long)G_);
+    const int s = slot_of(group, id);
+    if (s < 0) {
+        // kept all the same (read_only.go:74); it counts only if the id becomes
+        // a voter while the request is still pending
+        stray_acks_[group].insert(id);
+        return RAFTHIP_OK;
+    }
+    put_mask(rdacks_, group, get_mask(rdacks_, group) | (1ull << s));
+    touch(rdacks_dirty_, group);
+    return RAFTHIP_OK;
+}
+
+int BatchProgressTracker::ResetAcks(uint64_t group) {
+    if (group >= G_) return fail(RAFTHIP_ERANGE, "group %llu outside [0, %llu)", (unsigned long long)group,
+                                 (unsigned long long)G_);
+    put_mask(rdacks_, group, 0);
+    stray_acks_.erase(group);
+    touch(rdacks_dirty_, group);
+    return RAFTHIP_OK;
+}
+
+int BatchProgressTracker::AckQuorum(std::vector<quorum::VoteResult>* result) {
+    if (!result) return fail(RAFTHIP_EINVAL, "result is NULL");
+    if (rdacks_dirty_[0] <= rdacks_dirty_[1]) {
+        const uint64_t first = rdacks_dirty_[0], count = rdacks_dirty_[1] - rdacks_dirty_[0] + 1;
+        int rc = lib(rafthip_upload_acks(e_, first, count, rdacks_.data() + first * mb_));
+        if (rc) return rc;
+        rdacks_dirty_[0] = 1;
+        rdacks_dirty_[1] = 0;
+    }
+    int rc = lib(rafthip_ack_quorum(e_));
+    if (rc) return rc;
+    result->assign(G_, quorum::VotePending);
+    static_assert(sizeof(quorum::VoteResult) == 1, "VoteResult is uint8 (quorum/quorum.go:48)");
+    return lib(rafthip_read_ack_quorum(e_, 0, G_, reinterpret_cast<uint8_t*>(result->data())));
+}
+
+}  // namespace tracker
+}  // namespace raft

@@ -1,0 +1,124 @@
+// tracker_batch.hpp — C++ mirror of the quorum-facing part of the reference's
+// tracker.ProgressTracker (tracker/tracker.go:117-290) for MANY groups at once,
+// on top of one librafthip.so engine (one GPU).
+//
+// Method names and meaning follow the reference, with a leading group
+// argument; the batched evaluations (Committed, TallyVotes, QuorumActive,
+// AckQuorum) cover every group in one GPU pass.  The class owns what the
+// reference keeps in Go maps and the kernels cannot see: the id -> slot map of
+// every group.  It does no quorum arithmetic itself.
+//
+// Thread-unsafe, like RawNode (rawnode.go:31): one caller at a time.
+#pragma once
+#include <stdint.h>
+
+#include <map>
+#include <set>
+#include <unordered_map>
+#include <vector>
+
+#include "quorum.hpp"
+#include "rafthip.h"
+
+namespace raft {
+namespace tracker {
+
+struct CommitPair {  // = rafthip_commit_pair
+    uint64_t group;
+    uint64_t commit;
+};
+
+class BatchProgressTracker {
+   public:
+    // Stands where tracker.MakeProgressTracker (tracker/tracker.go:129-145)
+    // stands per group: every group starts with an empty config and no Progress.
+    static int Make(int device, uint64_t groups, uint32_t max_slots, BatchProgressTracker** out);
+    ~BatchProgressTracker();
+    BatchProgressTracker(const BatchProgressTracker&) = delete;
+    BatchProgressTracker& operator=(const BatchProgressTracker&) = delete;
+
+    uint64_t groups() const { return G_; }
+    uint32_t max_slots() const { return S_; }
+    const char* LastError() const { return err_; }
+
+    // The group's tracker.Config after a conf change (what confchange.Changer
+    // hands to raft.switchToConfig, raft.go:1949): incoming = Voters[0],
+    // outgoing = Voters[1], learners = Learners (LearnersNext ids are still
+    // voters of the outgoing half, confchange.go:297-304).  Ids that stay keep
+    // their Progress; removed ids lose it; new ids start with Match 0 and
+    // RecentActive true (confchange.go:257-270).
+    int SetConfig(uint64_t group, const quorum::MajorityConfig& incoming,
+                  const quorum::MajorityConfig& outgoing, const quorum::MajorityConfig& learners);
+
+    // raft.reset on a role change (raft.go:774-784): every Progress of the
+    // group is re-created — Match 0, RecentActive false — and votes are reset.
+    int ResetProgress(uint64_t group);
+
+    // Progress.MaybeUpdate's Match part (tracker/progress.go:168-177) for the
+    // ack of peer `id`; queued and applied by the next Committed()/Flush().
+    // Returns false when the group has no Progress for id (the reference drops
+    // such messages, raft.go:1327-1331) or the group is out of range.
+    bool MaybeUpdate(uint64_t group, uint64_t id, uint64_t n);
+    int Flush();
+
+    // ProgressTracker.Committed (tracker/tracker.go:179-181) for every group;
+    // *changed receives the groups whose commit index differs from the last
+    // call, sorted by group — the input of raft.maybeCommit (raft.go:755-758).
+    int Committed(std::vector<CommitPair>* changed);
+    int CommittedOf(uint64_t group, uint64_t* commit);  // after Committed()
+    int Match(uint64_t group, uint64_t id, uint64_t* match);
+
+    // tracker/tracker.go:254-265
+    int ResetVotes(uint64_t group);
+    int RecordVote(uint64_t group, uint64_t id, bool v);  // first vote of an id sticks
+    // ProgressTracker.TallyVotes (tracker/tracker.go:269-290) for every group.
+    int TallyVotes();
+    int VoteResultOf(uint64_t group, int* granted, int* rejected, quorum::VoteResult* result);
+
+    // Progress.RecentActive (set at raft.go:1337,1528; cleared at raft.go:1238-1242)
+    int SetRecentActive(uint64_t group, uint64_t id, bool active);
+    // ProgressTracker.QuorumActive (tracker/tracker.go:217-227) for every group.
+    int QuorumActive(std::vector<uint8_t>* active);
+
+    // readOnly.recvAck (read_only.go:68-76) for the group's pending ReadIndex
+    // request, and the quorum test of raft.go:1552 for every group.
+    int RecvAck(uint64_t group, uint64_t id);
+    int ResetAcks(uint64_t group);
+    int AckQuorum(std::vector<quorum::VoteResult>* result);
+
+    rafthip_engine* engine() { return e_; }
+
+   private:
+    BatchProgressTracker() = default;
+    int fail(int code, const char* fmt, ...);
+    int lib(int rc);
+    int slot_of(uint64_t group, uint64_t id) const;  // -1 if the group has no Progress for id
+    uint64_t get_mask(const std::vector<uint8_t>& plane, uint64_t g) const;
+    void put_mask(std::vector<uint8_t>& plane, uint64_t g, uint64_t m);
+    void touch(uint64_t (&range)[2], uint64_t g);
+    int push_config(uint64_t group);
+
+    rafthip_engine* e_ = nullptr;
+    uint64_t G_ = 0;
+    uint32_t S_ = 0, mb_ = 1;
+    char err_[512] = "";
+
+    std::vector<uint64_t> ids_;      // [G][S] voter/learner id in each slot
+    std::vector<uint64_t> used_;     // [G] slots that hold a Progress
+    std::vector<uint8_t> in_, out_, learner_;  // [G] masks, mb_ bytes each
+    std::vector<rafthip_ack> acks_;  // queued MaybeUpdate calls
+    std::vector<CommitPair> pairs_;  // landing buffer of Committed(), G entries
+    // Votes is keyed by id, not by Progress (tracker/tracker.go:122,260-265):
+    // votes of ids that hold no slot right now wait here until ResetVotes.
+    std::unordered_map<uint64_t, std::map<uint64_t, bool>> stray_votes_;
+    std::unordered_map<uint64_t, std::set<uint64_t>> stray_acks_;  // same for readIndexStatus.acks
+
+    // host shadows of the small planes, uploaded lazily over their dirty range
+    std::vector<uint8_t> votes_;   // [S][G]
+    std::vector<uint8_t> active_;  // [G] masks
+    std::vector<uint8_t> rdacks_;  // [G] masks
+    uint64_t votes_dirty_[2] = {1, 0}, active_dirty_[2] = {1, 0}, rdacks_dirty_[2] = {1, 0};
+};
+
+}  // namespace tracker
+}  // namespace raft

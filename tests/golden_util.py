@@ -127,14 +127,9 @@ def dist_b(seed, S, G):
     m = np.empty((S, G), dtype=np.uint64)
     for s in range(S):
         x = r[s]
-        # geometric(p=1/2) lag = number of trailing one bits of a random word
-        lag = np.zeros(G, dtype=np.uint64)
-        y = x.copy()
-        for _ in range(20):
-            bit = y & np.uint64(1)
-            alive = (lag == np.uint64(_)) & (bit == np.uint64(1))
-            lag = np.where(alive, lag + np.uint64(1), lag)
-            y >>= np.uint64(1)
+        # geometric(p=1/2) lag = number of trailing one bits of a random word, capped at 20
+        low0 = ~x & (x + np.uint64(1))  # lowest zero bit (0 when x is all ones)
+        lag = np.minimum(np.bitwise_count(low0 - np.uint64(1)).astype(np.uint64), np.uint64(20))
         lag = np.minimum(lag, L)
         v = L - lag if s else L
         zero = ((x >> np.uint64(32)) % np.uint64(100)) < np.uint64(5)

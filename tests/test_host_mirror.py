@@ -1,0 +1,283 @@
+"""The C++ host mirror of the Go API (raft_amd/host/: quorum::BatchCommittedIndex,
+quorum::BatchVoteResult, tracker::BatchProgressTracker), driven through its
+line-oriented CLI the way the reference's datadriven harness drives `quorum`
+(quorum/datadriven_test.go:36-250).
+
+CPU part: marshalling of the 127 golden cases into [slot][group] planes, error
+behaviour, loud failure without a GPU.  GPU part (marked gpu): the golden
+cases end to end, and random multi-group scenarios (conf changes, acks, votes,
+CheckQuorum, ReadIndex) against an id-keyed Python model that calls the
+per-group oracle functions — i.e. the reference's shapes on both sides.
+"""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import golden_util as gu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "raft_amd", "lib", "rafthost_cli")
+CASES = gu.load_cases()
+NAMES = {1: "VotePending", 2: "VoteLost", 3: "VoteWon"}
+
+
+def run_cli(script, timeout=120):
+    assert os.path.exists(CLI), "build first: python -c 'import __graft_entry__ as g; g.build()'"
+    p = subprocess.run([CLI], input=script, capture_output=True, text=True, timeout=timeout)
+    assert p.returncode == 0, p.stderr
+    return p.stdout.splitlines()
+
+
+def ids(xs):
+    return ",".join(str(x) for x in sorted(xs))
+
+
+def case_line(c):
+    l = gu.lookuper(c)
+    if c["cmd"] == "committed":
+        kv = ",".join("%d:%d" % (i, v) for i, v in l.items())
+        return "committed in=%s out=%s idx=%s" % (ids(c["cfg"]), ids(c["cfgj"]), kv)
+    kv = ",".join("%d:%s" % (i, "y" if v else "n") for i, v in l.items())
+    return "vote in=%s out=%s votes=%s" % (ids(c["cfg"]), ids(c["cfgj"]), kv)
+
+
+def parse_planes(lines):
+    """'planes ...' + 'group ...' lines -> list of (S, [(in, out, cells)])."""
+    out = []
+    for ln in lines:
+        t = ln.split()
+        if t[0] == "planes":
+            kv = dict(x.split("=") for x in t[1:])
+            out.append((int(kv["slots"]), int(kv["mask_bytes"]), []))
+        elif t[0] == "group":
+            kv = dict(x.split("=") for x in t[2:])
+            out[-1][2].append((int(kv["in"]), int(kv["out"]), [int(x) for x in kv["cells"].split(",")]))
+    return out
+
+
+def test_marshal_golden_cases_matches_reference_layout():
+    script = "\n".join(case_line(c) for c in CASES) + "\nmarshal\n"
+    planes = parse_planes(run_cli(script))
+    assert len(planes) == 2
+    for (S, mb, groups), cmd in zip(planes, ("committed", "vote")):
+        plane, m0, m1, _ = gu.cases_to_planes(CASES, cmd)
+        assert S == plane.shape[0] and mb == gu.mask_bytes(S)
+        assert len(groups) == plane.shape[1]
+        for g, (a, b, cells) in enumerate(groups):
+            assert a == int(m0[g]) and b == int(m1[g]), (cmd, g)
+            assert cells == [int(x) for x in plane[:, g]], (cmd, g)
+
+
+def test_marshal_rejects_more_than_64_voters():
+    out = run_cli("committed in=%s out= idx=\nmarshal\n" % ids(range(1, 66)))
+    assert out and out[0].startswith("error -22") and "at most 64" in out[0]
+
+
+def test_wide_group_uses_wider_masks():
+    out = run_cli("committed in=%s out=%s idx=20:7\nmarshal\n" % (ids(range(1, 21)), ids(range(15, 31))))
+    (S, mb, groups), = parse_planes(out)
+    assert (S, mb) == (30, 4)
+    a, b, cells = groups[0]
+    assert a == (1 << 20) - 1 and b == ((1 << 30) - 1) & ~((1 << 14) - 1)
+    assert cells[19] == 7 and sum(cells) == 7
+
+
+def test_host_mirror_fails_loudly_without_gpu():
+    try:
+        import torch
+        has_gpu = torch.cuda.is_available()
+    except Exception:
+        has_gpu = False
+    if has_gpu:
+        pytest.skip("GPU present")
+    out = run_cli("committed in=1 out= idx=1:3\nrun\ntracker 4 3\n")
+    assert len(out) == 2 and all(l.startswith("error -19") for l in out), out
+
+
+# ---------------------------------------------------------------------------
+# GPU
+# ---------------------------------------------------------------------------
+
+@pytest.mark.gpu
+def test_golden_cases_through_batch_entry_points():
+    script = "\n".join(case_line(c) for c in CASES) + "\nrun\n"
+    out = run_cli(script)
+    want = []
+    for cmd in ("committed", "vote"):
+        for i, c in enumerate(x for x in CASES if x["cmd"] == cmd):
+            e = c["expected"]
+            want.append("%s %d %s" % (cmd, i, e))
+    assert out == want
+
+
+class Model:
+    """tracker.ProgressTracker per group, id-keyed, evaluated with the per-group oracle."""
+
+    def __init__(self, G):
+        self.G = G
+        self.cfg = [(set(), set(), set()) for _ in range(G)]
+        self.match = [dict() for _ in range(G)]
+        self.active = [dict() for _ in range(G)]
+        self.votes = [dict() for _ in range(G)]
+        self.acks = [set() for _ in range(G)]
+        self.commit = [0] * G  # the engine's commit plane starts at zero
+
+    def set_config(self, g, inc, out, lrn):
+        self.cfg[g] = (set(inc), set(out), set(lrn))
+        allv = set(inc) | set(out) | set(lrn)
+        for i in list(self.match[g]):
+            if i not in allv:  # confchange.go:233-247
+                del self.match[g][i], self.active[g][i]
+        for i in allv:
+            if i not in self.match[g]:  # confchange.go:257-270
+                self.match[g][i] = 0
+                self.active[g][i] = True
+
+    def reset(self, g):  # raft.go:774-784
+        for i in self.match[g]:
+            self.match[g][i] = 0
+            self.active[g][i] = False
+        self.votes[g] = {}
+
+    def ack(self, g, i, n):
+        if i not in self.match[g]:
+            return False
+        self.match[g][i] = max(self.match[g][i], n)  # progress.go:168-177
+        return True
+
+    def committed(self, o, g):
+        inc, out, _ = self.cfg[g]
+        return o.joint_committed_index(sorted(inc), sorted(out), self.match[g])
+
+    def tally(self, o, g):  # tracker.go:269-290
+        inc, out, lrn = self.cfg[g]
+        gr = sum(1 for i in self.match[g] if i not in lrn and self.votes[g].get(i) is True)
+        rj = sum(1 for i in self.match[g] if i not in lrn and self.votes[g].get(i) is False)
+        return gr, rj, o.joint_vote_result(sorted(inc), sorted(out), self.votes[g])
+
+    def quorum_active(self, o, g):  # tracker.go:217-227
+        inc, out, lrn = self.cfg[g]
+        votes = {i: a for i, a in self.active[g].items() if i not in lrn}
+        return int(o.joint_vote_result(sorted(inc), sorted(out), votes) == 3)
+
+    def ack_quorum(self, o, g):  # read_only.go:68-76, raft.go:1552
+        inc, out, _ = self.cfg[g]
+        return o.joint_vote_result(sorted(inc), sorted(out), {i: True for i in self.acks[g]})
+
+
+def rand_config(rng, S, pool):
+    """A confchange-shaped config: outgoing = old voters, incoming = edited copy,
+    learners disjoint from both (confchange.go:51-145,276-332)."""
+    k = int(rng.integers(1, min(S, 7) + 1))
+    old = set(rng.choice(pool, size=k, replace=False).tolist())
+    kind = rng.random()
+    if kind < 0.4:
+        inc, out = old, set()
+    else:
+        inc = set(old)
+        for _ in range(int(rng.integers(1, 3))):
+            if rng.random() < 0.5 and len(inc) > 1:
+                inc.discard(int(rng.choice(sorted(inc))))
+            else:
+                inc.add(int(rng.choice(pool)))
+        out = old
+    lrn = set()
+    room = S - len(inc | out)
+    if room > 0 and rng.random() < 0.5:
+        free = [i for i in pool if i not in inc | out]
+        lrn = set(rng.choice(free, size=min(room, int(rng.integers(1, 3)), len(free)), replace=False).tolist())
+    while len(inc | out | lrn) > S:
+        (lrn or inc).pop()
+    if not inc:
+        inc = {int(pool[0])}
+    return inc, out, lrn - inc - out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("S,G,seed", [(8, 40, 1), (5, 64, 2), (12, 24, 3)])
+def test_tracker_scenarios(oracle, S, G, seed):
+    rng = np.random.default_rng(seed)
+    pool = np.arange(1, S + 4)
+    m = Model(G)
+    script, want = ["tracker %d %d" % (G, S)], ["tracker ok"]
+
+    def check_all():
+        script.append("commit")
+        ch = []
+        for g in range(G):
+            c = m.committed(oracle, g)
+            if c != m.commit[g]:
+                ch.append("changed %d %s" % (g, "inf" if c == gu.U64MAX else c))
+                m.commit[g] = c
+        want.extend(ch)
+        want.append("commit-done %d" % len(ch))
+        script.append("tally")
+        for g in rng.choice(G, size=6, replace=False).tolist():
+            script.append("voteof %d" % g)
+            gr, rj, r = m.tally(oracle, g)
+            want.append("voteof %d %d %d %s" % (g, gr, rj, NAMES[r]))
+            script.append("commitof %d" % g)
+            want.append("commitof %d %s" % (g, "inf" if m.commit[g] == gu.U64MAX else m.commit[g]))
+        script.append("quorumactive")
+        want.append("quorumactive " + "".join(str(m.quorum_active(oracle, g)) for g in range(G)))
+        script.append("ackquorum")
+        want.append("ackquorum " + "".join(str(m.ack_quorum(oracle, g)) for g in range(G)))
+
+    check_all()  # every group still has the empty config: inf, VoteWon, active
+    for g in range(G):
+        if rng.random() < 0.9:
+            inc, out, lrn = rand_config(rng, S, pool)
+            m.set_config(g, inc, out, lrn)
+            script.append("setconfig %d in=%s out=%s learners=%s" % (g, ids(inc), ids(out), ids(lrn)))
+    check_all()
+    for rnd in range(12):
+        for _ in range(6 * G):
+            g = int(rng.integers(0, G))
+            i = int(rng.choice(pool))
+            op = rng.random()
+            if op < 0.5:
+                n = int(rng.integers(0, 1000)) if rng.random() < 0.97 else int(rng.integers(1 << 62, 1 << 63)) * 2 + 1
+                script.append("ack %d %d %d" % (g, i, n))
+                if not m.ack(g, i, n):
+                    want.append("dropped")
+            elif op < 0.65:
+                v = bool(rng.random() < 0.6)
+                script.append("recordvote %d %d %s" % (g, i, "y" if v else "n"))
+                m.votes[g].setdefault(i, v)  # first vote sticks, any id (tracker.go:260-265)
+            elif op < 0.8:
+                a = bool(rng.random() < 0.5)
+                script.append("active %d %d %d" % (g, i, a))
+                if i in m.active[g]:
+                    m.active[g][i] = a
+                else:
+                    want.append("error -22 group %d has no Progress for id %d" % (g, i))
+            elif op < 0.92:
+                script.append("recvack %d %d" % (g, i))
+                m.acks[g].add(i)
+            elif op < 0.94:
+                script.append("resetvotes %d" % g)
+                m.votes[g] = {}
+            elif op < 0.96:
+                script.append("resetacks %d" % g)
+                m.acks[g] = set()
+            elif op < 0.98:
+                script.append("reset %d" % g)
+                m.reset(g)
+            else:
+                inc, out, lrn = rand_config(rng, S, pool)
+                m.set_config(g, inc, out, lrn)
+                script.append("setconfig %d in=%s out=%s learners=%s" % (g, ids(inc), ids(out), ids(lrn)))
+        g = int(rng.integers(0, G))
+        i = int(rng.choice(pool))
+        script.append("matchof %d %d" % (g, i))
+        if i in m.match[g]:
+            want.append("matchof %d %d %d" % (g, i, m.match[g][i]))
+        else:
+            want.append("error -22 group %d has no Progress for id %d" % (g, i))
+        check_all()
+    out = run_cli("\n".join(script) + "\n", timeout=300)
+    for k, (a, b) in enumerate(zip(out, want)):
+        assert a == b, (k, a, b)
+    assert len(out) == len(want)
