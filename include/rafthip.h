@@ -85,6 +85,24 @@ typedef struct rafthip_ack {
     uint64_t index;
 } rafthip_ack;
 
+/* One response message a leader received, resolved by the host to (group,
+ * slot) — the fields of raftpb.Message (raftpb/raft.proto:71-108) that
+ * stepLeader's per-message bookkeeping reads (raft.go:1327-1561). */
+#define RAFTHIP_MSG_APP_RESP 4        /* pb.MsgAppResp,       raftpb/raft.proto:46 */
+#define RAFTHIP_MSG_HEARTBEAT_RESP 9  /* pb.MsgHeartbeatResp, raftpb/raft.proto:51 */
+#define RAFTHIP_MSG_APPENDED 0xF0     /* local, not a wire type: the leader's log grew to `index`
+                                         (appendEntry, raft.go:787-819); slot is ignored */
+#define RAFTHIP_MSGF_READ_CTX 1       /* heartbeat response whose Context names the group's pending
+                                         ReadIndex request (read_only.go:68-76) */
+typedef struct rafthip_msg {
+    uint32_t group;
+    uint8_t slot;    /* Message.From -> slot */
+    uint8_t type;    /* RAFTHIP_MSG_* */
+    uint8_t reject;  /* Message.Reject */
+    uint8_t flags;   /* RAFTHIP_MSGF_* */
+    uint64_t index;  /* Message.Index */
+} rafthip_msg;
+
 /* A group whose quorum commit index changed — what raft.maybeCommit
  * (raft.go:755-758) hands to raftLog.maybeCommit (log.go:447-456). */
 typedef struct rafthip_commit_pair {
@@ -100,6 +118,10 @@ typedef struct rafthip_stats_t {
     uint64_t changed_reported;  /* pairs returned by rafthip_commit_changed */
     uint64_t bytes_uploaded;
     uint64_t bytes_downloaded;
+    uint64_t advanced_reported; /* pairs returned by rafthip_commit_advance */
+    uint64_t msgs_ingested;     /* records submitted to rafthip_ingest_msgs */
+    uint64_t msgs_dropped;      /* of those, dropped: no Progress (group/slot out of range) */
+    uint64_t msgs_ignored;      /* of those, of a type the engine does not handle */
 } rafthip_stats_t;
 
 /* ---- lifecycle ---------------------------------------------------------- */
@@ -155,7 +177,25 @@ int rafthip_reset_votes(rafthip_engine *e, uint64_t first, uint64_t count);
 int rafthip_upload_active(rafthip_engine *e, uint64_t first, uint64_t count, const void *src);
 /* readIndexStatus.acks bits (read_only.go:29-37,68-76). */
 int rafthip_upload_acks(rafthip_engine *e, uint64_t first, uint64_t count, const void *src);
-/* Seed the commit plane (the value rafthip_commit_changed compares against). */
+/* The leader's own slot as a one-bit mask per group (0 = the leader has no
+ * Progress row): the id != r.id test of raft.go:1238-1242. */
+int rafthip_upload_self(rafthip_engine *e, uint64_t first, uint64_t count, const void *src);
+/* RecentActive / ReadIndex-ack bits as the engine holds them now (after
+ * rafthip_ingest_msgs, rafthip_check_quorum). */
+int rafthip_read_active(rafthip_engine *e, uint64_t first, uint64_t count, void *dst);
+int rafthip_read_acks(rafthip_engine *e, uint64_t first, uint64_t count, void *dst);
+/* For rafthip_commit_advance: the log indexes of each group whose entry carries
+ * the leader's current term, [term_first, term_last] (terms never decrease
+ * along a log, so they are one run; for a leader term_last is lastIndex).
+ * An empty range (first > last; the zero-initialised default counts as empty)
+ * means "term(i) != r.Term for every i": not a leader, or r.Term == 0. */
+int rafthip_upload_term_range(rafthip_engine *e, uint64_t first, uint64_t count,
+                              const uint64_t *term_first, const uint64_t *term_last);
+/* Either pointer may be NULL.  term_last also grows through RAFTHIP_MSG_APPENDED records. */
+int rafthip_read_term_range(rafthip_engine *e, uint64_t first, uint64_t count, uint64_t *term_first,
+                            uint64_t *term_last);
+/* Seed the commit plane (the value rafthip_commit_changed compares against;
+ * raftLog.committed for rafthip_commit_advance). */
 int rafthip_upload_commit(rafthip_engine *e, uint64_t first, uint64_t count, const uint64_t *src);
 
 /* ---- compute ------------------------------------------------------------ */
@@ -167,6 +207,20 @@ int rafthip_upload_commit(rafthip_engine *e, uint64_t first, uint64_t count, con
  * (stats.acks_rejected; the reference drops acks from unknown peers,
  * raft.go:1327-1331). */
 int rafthip_scatter_acks(rafthip_engine *e, const rafthip_ack *recs, uint64_t n);
+
+/* stepLeader's bookkeeping for a batch of responses — raft.go:1327-1561:
+ *   MsgAppResp:       pr.RecentActive = true (raft.go:1337); unless Reject,
+ *                     pr.MaybeUpdate(m.Index) (raft.go:1477 -> tracker/progress.go:168-177)
+ *   MsgHeartbeatResp: pr.RecentActive = true (raft.go:1528); with
+ *                     RAFTHIP_MSGF_READ_CTX, readOnly.recvAck: acks[from] = true
+ *                     (raft.go:1552 -> read_only.go:68-76)
+ *   RAFTHIP_MSG_APPENDED: term_last = max(term_last, index)
+ * All updates are max / or, so the batch equals stepping the messages one by
+ * one.  Records without a Progress row (group >= G, slot >= S) are dropped as
+ * raft.go:1327-1331 drops them (stats.msgs_dropped); other types are counted
+ * in stats.msgs_ignored.  The Progress FSM side effects (Probe/Replicate,
+ * Inflights, MaybeDecrTo on Reject) stay with the host. */
+int rafthip_ingest_msgs(rafthip_engine *e, const rafthip_msg *msgs, uint64_t n);
 
 /* ProgressTracker.Committed for every group — tracker/tracker.go:179-181 =
  * JointConfig.CommittedIndex (quorum/joint.go:49-56) over
@@ -181,7 +235,25 @@ int rafthip_commit(rafthip_engine *e);
  * raft.go:755-758. */
 int rafthip_commit_changed(rafthip_engine *e, rafthip_commit_pair *dst, uint64_t max_pairs,
                            uint64_t *n_changed);
+/* raft.maybeCommit for every group — raft.go:755-758: mci = trk.Committed(),
+ * then raftLog.maybeCommit(mci, r.Term) (log.go:447-456) fused into the same
+ * pass.  The commit plane is raftLog.committed here: it moves to mci, and
+ * (group, mci) is reported (sorted by group), iff mci > committed and
+ * term_first <= mci <= term_last — i.e. term != 0 and
+ * zeroTermOnOutOfBounds(term(mci)) == r.Term.  Only advanced groups travel
+ * back, so this replaces the host's per-group term lookup.  Use either
+ * rafthip_commit/_changed or this on one engine: they give the commit plane
+ * different meanings. */
+int rafthip_commit_advance(rafthip_engine *e, rafthip_commit_pair *dst, uint64_t max_pairs,
+                           uint64_t *n_advanced);
 int rafthip_read_commit(rafthip_engine *e, uint64_t first, uint64_t count, uint64_t *dst);
+
+/* The commit index a heartbeat may carry to each peer — sendHeartbeat,
+ * raft.go:669-685: min(Progress.Match, raftLog.committed) for every (slot,
+ * group).  dst receives S rows of `count` values (row s at dst + s*dst_stride);
+ * with dst NULL the result only stays on the device (RAFTHIP_PLANE_HEARTBEAT). */
+int rafthip_heartbeat_commit(rafthip_engine *e, uint64_t first, uint64_t count, uint64_t *dst,
+                             uint64_t dst_stride);
 
 /* ProgressTracker.TallyVotes for every group — tracker/tracker.go:269-290 →
  * JointConfig.VoteResult (quorum/joint.go:61-75) over
@@ -196,6 +268,10 @@ int rafthip_read_vote_result(rafthip_engine *e, uint64_t first, uint64_t count, 
  * (CheckQuorum, raft.go:1231-1243).  Output 1 = active, 0 = not. */
 int rafthip_quorum_active(rafthip_engine *e);
 int rafthip_read_quorum_active(rafthip_engine *e, uint64_t first, uint64_t count, uint8_t *dst);
+/* The whole MsgCheckQuorum step — raft.go:1231-1243: QuorumActive as above,
+ * then RecentActive = false for every Progress but the leader's own
+ * (rafthip_upload_self).  Read the verdict with rafthip_read_quorum_active. */
+int rafthip_check_quorum(rafthip_engine *e);
 
 /* ReadIndex ack quorum — Voters.VoteResult(acks) at raft.go:1552 with the
  * yes-only map of read_only.go:68-76.  Output: VoteResult per group. */
@@ -207,6 +283,7 @@ int rafthip_read_ack_quorum(rafthip_engine *e, uint64_t first, uint64_t count, u
 #define RAFTHIP_PLANE_MATCH 0  /* uint64 [S][stride] */
 #define RAFTHIP_PLANE_COMMIT 1 /* uint64 [stride]    */
 #define RAFTHIP_PLANE_VOTES 2  /* uint8  [S][stride] */
+#define RAFTHIP_PLANE_HEARTBEAT 3 /* uint64 [S][stride], filled by rafthip_heartbeat_commit */
 /* Device address and plane stride (in elements) of an engine plane. */
 int rafthip_plane(rafthip_engine *e, int which, void **ptr, uint64_t *stride);
 

@@ -62,6 +62,19 @@ def lib():
         L.oracle_batch_ack_quorum.argtypes = [C.c_uint64, C.c_int, vp, vp, vp, C.c_int, C.c_int, vp]
         L.oracle_scatter_acks.restype = C.c_uint64
         L.oracle_scatter_acks.argtypes = [C.c_uint64, C.c_int, vp, C.c_uint64, vp, C.c_uint64]
+        L.oracle_raftlog_maybe_commit.restype = C.c_int
+        L.oracle_raftlog_maybe_commit.argtypes = [C.c_uint64, C.c_uint64, vp, C.c_uint64, u64p, C.c_uint64,
+                                                  C.c_uint64]
+        L.oracle_batch_maybe_commit.restype = None
+        L.oracle_batch_maybe_commit.argtypes = [C.c_uint64, C.c_int, vp, C.c_uint64, vp, vp, C.c_int, C.c_int,
+                                                vp, vp, vp, vp, vp, vp, vp]
+        L.oracle_step_leader_msgs.restype = None
+        L.oracle_step_leader_msgs.argtypes = [C.c_uint64, C.c_int, vp, C.c_uint64, vp, vp, C.c_int, vp, vp,
+                                              C.c_uint64, vp]
+        L.oracle_batch_check_quorum.restype = None
+        L.oracle_batch_check_quorum.argtypes = [C.c_uint64, C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp]
+        L.oracle_batch_heartbeat_commit.restype = None
+        L.oracle_batch_heartbeat_commit.argtypes = [C.c_uint64, C.c_int, vp, C.c_uint64, vp, vp, C.c_uint64]
         L.oracle_bench_create.restype = C.c_void_p
         L.oracle_bench_create.argtypes = [C.c_uint64, C.c_int, vp, C.c_uint64]
         L.oracle_bench_run.restype = C.c_int
@@ -210,6 +223,68 @@ def scatter_acks(match, recs):
     S, G = match.shape
     return int(lib().oracle_scatter_acks(G, S, _vp(match), match.strides[0] // 8, _vp(recs),
                                          len(recs)))
+
+
+MSG_DTYPE = np.dtype([("group", "<u4"), ("slot", "u1"), ("type", "u1"), ("reject", "u1"), ("flags", "u1"),
+                      ("index", "<u8")])
+
+
+def raftlog_maybe_commit(first_index, snap_term, terms, committed, max_index, term):
+    """raftLog.maybeCommit(maxIndex, term) on an explicit log -> (advanced, committed)."""
+    t = np.ascontiguousarray(np.asarray(terms, dtype=np.uint64))
+    c = C.c_uint64(committed)
+    ok = lib().oracle_raftlog_maybe_commit(first_index, snap_term, _vp(t), len(t), C.byref(c), max_index, term)
+    return bool(ok), c.value
+
+
+def batch_maybe_commit(match, logs, term, committed, in_mask=None, out_mask=None, uniform_voters=0):
+    """raft.maybeCommit for every group.  logs = (log_off[G+1], log_terms, log_first[G],
+    log_snap_term[G]).  Returns (new committed, advanced u8)."""
+    match = _chk(match, np.uint64)
+    S, G = match.shape
+    off, terms, first, snap = (_chk(np.ascontiguousarray(a), np.uint64) for a in logs)
+    term = _chk(np.ascontiguousarray(term), np.uint64)
+    com = np.array(committed, dtype=np.uint64, copy=True)
+    adv = np.zeros(G, dtype=np.uint8)
+    lib().oracle_batch_maybe_commit(G, S, _vp(match), match.strides[0] // 8, _vp(_chk(in_mask)),
+                                    _vp(_chk(out_mask)), _mask_bytes(in_mask, out_mask), uniform_voters,
+                                    _vp(off), _vp(terms), _vp(first), _vp(snap), _vp(term), _vp(com), _vp(adv))
+    return com, adv
+
+
+def step_leader_msgs(match, active, acks, last_index, msgs):
+    """stepLeader bookkeeping for msgs in order; mutates match/active/acks/last_index.
+    Returns (dropped, ignored)."""
+    match = _chk(match, np.uint64)
+    msgs = _chk(msgs, MSG_DTYPE)
+    S, G = match.shape
+    counts = np.zeros(2, dtype=np.uint64)
+    lib().oracle_step_leader_msgs(G, S, _vp(match), match.strides[0] // 8, _vp(_chk(active)), _vp(_chk(acks)),
+                                  active.dtype.itemsize, _vp(_chk(last_index, np.uint64)), _vp(msgs),
+                                  len(msgs), _vp(counts))
+    return int(counts[0]), int(counts[1])
+
+
+def batch_check_quorum(active, nslots, self_mask, in_mask=None, out_mask=None, learner_mask=None,
+                       uniform_voters=0):
+    """MsgCheckQuorum for every group: returns QuorumActive u8; mutates active (all but self cleared)."""
+    active = _chk(active)
+    G = active.shape[0]
+    out = np.empty(G, dtype=np.uint8)
+    lib().oracle_batch_check_quorum(G, nslots, _vp(active), _vp(_chk(in_mask)), _vp(_chk(out_mask)),
+                                    _vp(_chk(learner_mask)), active.dtype.itemsize, uniform_voters,
+                                    _vp(_chk(self_mask)), _vp(out))
+    return out
+
+
+def batch_heartbeat_commit(match, committed):
+    """sendHeartbeat's commit = min(Match, committed) for every (slot, group)."""
+    match = _chk(match, np.uint64)
+    S, G = match.shape
+    out = np.empty((S, G), dtype=np.uint64)
+    lib().oracle_batch_heartbeat_commit(G, S, _vp(match), match.strides[0] // 8,
+                                        _vp(_chk(committed, np.uint64)), _vp(out), G)
+    return out
 
 
 class CpuBaseline:

@@ -507,6 +507,157 @@ ORACLE_API uint64_t oracle_scatter_acks(uint64_t G, int nslots, uint64_t *match,
 }
 
 /* ------------------------------------------------------------------------ */
+/* The steps either side of the quorum arithmetic.           */
+/* ------------------------------------------------------------------------ */
+
+/*
+ * A raftLog reduced to what term() needs: entries first_index..first_index+n-1
+ * with their terms, and the term of the compacted entry first_index-1
+ * (snapshot / dummy entry, storage.go MemoryStorage.ents[0]).
+ */
+typedef struct {
+    uint64_t first_index; /* raftLog.firstIndex() */
+    uint64_t snap_term;   /* term of entry first_index-1 */
+    const uint64_t *terms;
+    uint64_t n;
+} oracle_log;
+
+/* log.go:381-407 — raftLog.term, wrapped in zeroTermOnOutOfBounds (log.go:559-568):
+ * ErrCompacted and ErrUnavailable become term 0. */
+static uint64_t log_term_or_zero(const oracle_log *l, uint64_t i) {
+    uint64_t last = l->first_index + l->n - 1; /* lastIndex(); first_index-1 when empty */
+    if (i + 1 < l->first_index) return 0;      /* ErrCompacted */
+    if (i > last) return 0;                    /* ErrUnavailable */
+    if (i + 1 == l->first_index) return l->snap_term;
+    return l->terms[i - l->first_index];
+}
+
+/* log.go:447-456 — raftLog.maybeCommit; commitTo (log.go:318-326) never
+ * decreases.  Returns 1 and moves *committed when the guard passes. */
+static int raftlog_maybe_commit(const oracle_log *l, uint64_t *committed, uint64_t max_index,
+                                uint64_t term) {
+    if (max_index > *committed && term != 0 && log_term_or_zero(l, max_index) == term) {
+        if (*committed < max_index) *committed = max_index;
+        return 1;
+    }
+    return 0;
+}
+
+ORACLE_API int oracle_raftlog_maybe_commit(uint64_t first_index, uint64_t snap_term,
+                                           const uint64_t *terms, uint64_t n, uint64_t *committed,
+                                           uint64_t max_index, uint64_t term) {
+    oracle_log l = {first_index, snap_term, terms, n};
+    return raftlog_maybe_commit(&l, committed, max_index, term);
+}
+
+/*
+ * raft.go:755-758 — raft.maybeCommit over G groups: mci = trk.Committed(), then
+ * raftLog.maybeCommit(mci, r.Term).  Group g's log is entries
+ * log_terms[log_off[g] .. log_off[g+1]) starting at index log_first[g].
+ * committed[] is updated in place; advanced[g] = the bool maybeCommit returned.
+ */
+ORACLE_API void oracle_batch_maybe_commit(uint64_t G, int nslots, const uint64_t *match,
+                                          uint64_t stride, const void *in_mask,
+                                          const void *out_mask, int mask_bytes, int uniform_voters,
+                                          const uint64_t *log_off, const uint64_t *log_terms,
+                                          const uint64_t *log_first, const uint64_t *log_snap_term,
+                                          const uint64_t *term, uint64_t *committed,
+                                          uint8_t *advanced) {
+    uint64_t *mci = (uint64_t *)malloc(sizeof(uint64_t) * (G ? G : 1));
+    oracle_batch_committed(G, nslots, match, stride, in_mask, out_mask, mask_bytes, uniform_voters,
+                           mci, 0);
+    for (uint64_t g = 0; g < G; g++) {
+        oracle_log l = {log_first[g], log_snap_term[g], log_terms + log_off[g],
+                        log_off[g + 1] - log_off[g]};
+        advanced[g] = (uint8_t)raftlog_maybe_commit(&l, &committed[g], mci[g], term[g]);
+    }
+    free(mci);
+}
+
+static void store_mask(void *masks, int mask_bytes, uint64_t g, uint64_t v) {
+    switch (mask_bytes) {
+    case 1: ((uint8_t *)masks)[g] = (uint8_t)v; break;
+    case 2: ((uint16_t *)masks)[g] = (uint16_t)v; break;
+    case 4: ((uint32_t *)masks)[g] = (uint32_t)v; break;
+    default: ((uint64_t *)masks)[g] = v; break;
+    }
+}
+
+/*
+ * raft.go:1327-1561 — stepLeader's per-message bookkeeping, one message at a
+ * time in order:
+ *   no Progress for m.From -> return (:1327-1331)
+ *   MsgAppResp (4):       pr.RecentActive = true (:1337); !Reject -> MaybeUpdate(Index) (:1477)
+ *   MsgHeartbeatResp (9): pr.RecentActive = true (:1528); Context names the
+ *                         pending request -> readOnly.recvAck: acks[from]=true
+ *                         (:1552, read_only.go:68-76)
+ * plus the local 0xF0 record: the leader's lastIndex grew (appendEntry,
+ * raft.go:787-819), tracked as last_index = max(last_index, index).
+ * counts[0] = dropped (no Progress), counts[1] = other message types.
+ */
+typedef struct {
+    uint32_t group;
+    uint8_t slot, type, reject, flags;
+    uint64_t index;
+} oracle_msg;
+
+ORACLE_API void oracle_step_leader_msgs(uint64_t G, int nslots, uint64_t *match, uint64_t stride,
+                                        void *active, void *acks, int mask_bytes,
+                                        uint64_t *last_index, const oracle_msg *msgs, uint64_t n,
+                                        uint64_t *counts) {
+    counts[0] = counts[1] = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        const oracle_msg *m = &msgs[i];
+        if (m->type == 0xF0) {
+            if (m->group >= G) { counts[0]++; continue; }
+            if (last_index[m->group] < m->index) last_index[m->group] = m->index;
+            continue;
+        }
+        if (m->type != 4 && m->type != 9) { counts[1]++; continue; }
+        if (m->group >= G || m->slot >= nslots) { counts[0]++; continue; }
+        store_mask(active, mask_bytes, m->group, load_mask(active, mask_bytes, m->group) | (1ULL << m->slot));
+        if (m->type == 4) {
+            if (!m->reject) {
+                uint64_t next = 0;
+                oracle_maybe_update(&match[(uint64_t)m->slot * stride + m->group], &next, m->index);
+            }
+        } else if (m->flags & 1) {
+            store_mask(acks, mask_bytes, m->group, load_mask(acks, mask_bytes, m->group) | (1ULL << m->slot));
+        }
+    }
+}
+
+/*
+ * raft.go:1231-1243 — MsgCheckQuorum over G groups: out = QuorumActive(), then
+ * every Progress except the leader's own (self bit) gets RecentActive = false.
+ */
+ORACLE_API void oracle_batch_check_quorum(uint64_t G, int nslots, void *active, const void *in_mask,
+                                          const void *out_mask, const void *learner_mask,
+                                          int mask_bytes, int uniform_voters, const void *self_mask,
+                                          uint8_t *out) {
+    oracle_batch_quorum_active(G, nslots, active, in_mask, out_mask, learner_mask, mask_bytes,
+                               uniform_voters, out);
+    for (uint64_t g = 0; g < G; g++) {
+        uint64_t a = load_mask(active, mask_bytes, g), self = load_mask(self_mask, mask_bytes, g);
+        uint64_t keep = 0;
+        for (int s = 0; s < nslots; s++) /* Visit: id != r.id -> RecentActive = false */
+            if (((self >> s) & 1) && ((a >> s) & 1)) keep |= 1ULL << s;
+        store_mask(active, mask_bytes, g, keep);
+    }
+}
+
+/* raft.go:669-685 — sendHeartbeat's commit := min(pr.Match, r.raftLog.committed). */
+ORACLE_API void oracle_batch_heartbeat_commit(uint64_t G, int nslots, const uint64_t *match,
+                                              uint64_t stride, const uint64_t *committed,
+                                              uint64_t *out, uint64_t out_stride) {
+    for (int s = 0; s < nslots; s++)
+        for (uint64_t g = 0; g < G; g++) {
+            uint64_t m = match[(uint64_t)s * stride + g];
+            out[(uint64_t)s * out_stride + g] = m < committed[g] ? m : committed[g];
+        }
+}
+
+/* ------------------------------------------------------------------------ */
 /* CPU baseline (bench.py cpu_baseline leg, kind "port"): the reference's    */
 /* data shape — one id set + one id-keyed map per group, built up front —    */
 /* and a goroutine-per-core style parallel loop over groups calling          */

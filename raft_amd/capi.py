@@ -14,6 +14,10 @@ _LIB = None
 
 ACK_DTYPE = np.dtype([("group", "<u4"), ("slot", "<u4"), ("index", "<u8")])
 PAIR_DTYPE = np.dtype([("group", "<u8"), ("commit", "<u8")])
+MSG_DTYPE = np.dtype([("group", "<u4"), ("slot", "u1"), ("type", "u1"), ("reject", "u1"), ("flags", "u1"),
+                      ("index", "<u8")])
+MSG_APP_RESP, MSG_HEARTBEAT_RESP, MSG_APPENDED, MSGF_READ_CTX = 4, 9, 0xF0, 1
+PLANE_HEARTBEAT = 3
 
 PLANE_MATCH, PLANE_COMMIT, PLANE_VOTES = 0, 1, 2
 VOTE_PENDING, VOTE_LOST, VOTE_WON = 1, 2, 3
@@ -29,6 +33,9 @@ SYMBOLS = [
     "rafthip_tally_votes", "rafthip_read_vote_result", "rafthip_quorum_active",
     "rafthip_read_quorum_active", "rafthip_ack_quorum", "rafthip_read_ack_quorum",
     "rafthip_plane", "rafthip_batch_committed_index", "rafthip_batch_vote_result",
+    "rafthip_ingest_msgs", "rafthip_commit_advance", "rafthip_upload_term_range",
+    "rafthip_heartbeat_commit", "rafthip_upload_self", "rafthip_check_quorum",
+    "rafthip_read_active", "rafthip_read_acks", "rafthip_read_term_range",
 ]
 
 
@@ -46,7 +53,8 @@ class _Config(C.Structure):
 class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("commit_launches", "groups_evaluated", "acks_applied",
                                            "acks_rejected", "changed_reported", "bytes_uploaded",
-                                           "bytes_downloaded")]
+                                           "bytes_downloaded", "advanced_reported", "msgs_ingested",
+                                           "msgs_dropped", "msgs_ignored")]
 
 
 def library_path():
@@ -95,6 +103,15 @@ def load_library():
         "rafthip_plane": (i32, [vp, i32, C.POINTER(vp), C.POINTER(u64)]),
         "rafthip_batch_committed_index": (i32, [i32, u64, u32, vp, vp, vp, vp]),
         "rafthip_batch_vote_result": (i32, [i32, u64, u32, vp, vp, vp, vp]),
+        "rafthip_ingest_msgs": (i32, [vp, vp, u64]),
+        "rafthip_commit_advance": (i32, [vp, vp, u64, C.POINTER(u64)]),
+        "rafthip_upload_term_range": (i32, [vp, u64, u64, vp, vp]),
+        "rafthip_heartbeat_commit": (i32, [vp, u64, u64, vp, u64]),
+        "rafthip_upload_self": (i32, [vp, u64, u64, vp]),
+        "rafthip_check_quorum": (i32, [vp]),
+        "rafthip_read_active": (i32, [vp, u64, u64, vp]),
+        "rafthip_read_acks": (i32, [vp, u64, u64, vp]),
+        "rafthip_read_term_range": (i32, [vp, u64, u64, vp, vp]),
     }
     assert sorted(sig) == sorted(SYMBOLS)
     for name, (res, args) in sig.items():
@@ -227,6 +244,56 @@ class Engine:
         _check(self._L.rafthip_commit_changed(self._h, _ptr(out) if max_pairs else None, max_pairs,
                                               C.byref(n)))
         return out[:min(n.value, max_pairs)], n.value
+
+    def commit_advance(self, max_pairs=None):
+        """raft.maybeCommit for every group. Returns (pairs[PAIR_DTYPE], n_advanced)."""
+        if max_pairs is None:
+            max_pairs = self.G
+        out = np.empty(max_pairs, dtype=PAIR_DTYPE)
+        n = C.c_uint64()
+        _check(self._L.rafthip_commit_advance(self._h, _ptr(out) if max_pairs else None, max_pairs,
+                                              C.byref(n)))
+        return out[:min(n.value, max_pairs)], n.value
+
+    def upload_term_range(self, term_first, term_last, first=0, count=None):
+        first, count = self._range(first, count)
+        _check(self._L.rafthip_upload_term_range(self._h, first, count, _ptr(term_first), _ptr(term_last)))
+
+    def read_term_range(self, first=0, count=None):
+        first, count = self._range(first, count)
+        tf, tl = np.empty(count, dtype=np.uint64), np.empty(count, dtype=np.uint64)
+        _check(self._L.rafthip_read_term_range(self._h, first, count, _ptr(tf), _ptr(tl)))
+        return tf, tl
+
+    def ingest_msgs(self, msgs, n=None):
+        if n is None:
+            n = len(msgs)
+        _check(self._L.rafthip_ingest_msgs(self._h, _ptr(msgs), n))
+
+    def heartbeat_commit(self, first=0, count=None, download=True):
+        first, count = self._range(first, count)
+        out = np.empty((self.S, count), dtype=np.uint64) if download else None
+        _check(self._L.rafthip_heartbeat_commit(self._h, first, count, _ptr(out), count))
+        return out
+
+    def upload_self(self, bits, first=0, count=None):
+        first, count = self._range(first, count)
+        _check(self._L.rafthip_upload_self(self._h, first, count, _ptr(bits)))
+
+    def check_quorum(self):
+        _check(self._L.rafthip_check_quorum(self._h))
+
+    def read_active(self, first=0, count=None):
+        first, count = self._range(first, count)
+        out = np.empty(count, dtype=self.mask_dtype)
+        _check(self._L.rafthip_read_active(self._h, first, count, _ptr(out)))
+        return out
+
+    def read_acks(self, first=0, count=None):
+        first, count = self._range(first, count)
+        out = np.empty(count, dtype=self.mask_dtype)
+        _check(self._L.rafthip_read_acks(self._h, first, count, _ptr(out)))
+        return out
 
     def read_commit(self, first=0, count=None):
         first, count = self._range(first, count)

@@ -38,6 +38,18 @@ struct Ack {  // = rafthip_ack
     u64 index;
 };
 
+struct Msg {  // = rafthip_msg
+    u32 group;
+    uint8_t slot;
+    uint8_t type;
+    uint8_t reject;
+    uint8_t flags;
+    u64 index;
+};
+constexpr uint8_t kMsgAppResp = 4, kMsgHeartbeatResp = 9;  // raftpb/raft.proto:41-69
+constexpr uint8_t kMsgAppended = 0xF0;                     // local: the leader's log grew to `index`
+constexpr uint8_t kMsgFlagCtx = 1;                         // heartbeat response carries the pending ReadIndex ctx
+
 template <typename T, int N>
 struct alignas(sizeof(T) * N) Vec {
     T v[N];
@@ -181,28 +193,57 @@ __device__ __forceinline__ void emit_changed(const bool (&ch)[CH][2], const u64 
     if (threadIdx.x == 0) counts[blockIdx.x] = run;
 }
 
-// Store the tile's results; with CHANGED also diff against the previous
-// content of the commit plane and emit the changed pairs.
-template <int CH, int BLOCK, bool CHANGED>
+// What a commit pass does with a group's quorum commit index (mci):
+//   kStore    commit[g] = mci                                  (ProgressTracker.Committed)
+//   kChanged  same, and report (g, mci) where mci != old commit[g]
+//   kAdvance  raftLog.maybeCommit fused in (log.go:447-456 via raft.go:755-758):
+//             commit[g] is raftLog.committed; it moves to mci, and (g, mci) is
+//             reported, iff mci > commit[g] and the entry at mci carries the
+//             leader's term, i.e. term_start[g] <= mci <= last_index[g]
+//             (log terms never decrease and the leader appends only in its own
+//             term, so the entries of the current term are exactly that range;
+//             beyond last_index raftLog.term is ErrUnavailable -> 0, log.go:381-407).
+constexpr int kStore = 0, kChanged = 1, kAdvance = 2;
+
+struct LogBounds {  // per-group planes used by kAdvance only
+    const u64* __restrict__ term_start;
+    const u64* __restrict__ last_index;
+};
+
+// Store the tile's results; report changed / advanced pairs as MODE says.
+template <int CH, int BLOCK, int MODE>
 __device__ __forceinline__ void finish_tile(const Vec<u64, 2> (&res)[CH], u64 base, u64 G,
-                                            u64* __restrict__ commit, Pair* __restrict__ stage,
-                                            u32* __restrict__ counts) {
-    if constexpr (CHANGED) {
+                                            u64* __restrict__ commit, LogBounds lb,
+                                            Pair* __restrict__ stage, u32* __restrict__ counts) {
+    if constexpr (MODE != kStore) {
         bool ch[CH][2];
         u64 grp[CH][2], val[CH][2];
+        Vec<u64, 2> nxt[CH];
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
             const u64 g0 = base + (u64)c * BLOCK * 2;
             const Vec<u64, 2> old = load_stream<u64, 2>(commit + g0);
+            Vec<u64, 2> ts, li;
+            if constexpr (MODE == kAdvance) {
+                ts = load_stream<u64, 2>(lb.term_start + g0);
+                li = load_stream<u64, 2>(lb.last_index + g0);
+            }
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
+                const u64 r = res[c].v[j];
                 grp[c][j] = g0 + j;
-                val[c][j] = res[c].v[j];
-                ch[c][j] = (grp[c][j] < G) && (old.v[j] != res[c].v[j]);
+                val[c][j] = r;
+                if constexpr (MODE == kAdvance) {
+                    ch[c][j] = (grp[c][j] < G) && (r > old.v[j]) && (r >= ts.v[j]) && (r <= li.v[j]);
+                    nxt[c].v[j] = ch[c][j] ? r : old.v[j];
+                } else {
+                    ch[c][j] = (grp[c][j] < G) && (old.v[j] != r);
+                    nxt[c].v[j] = r;
+                }
             }
         }
 #pragma unroll
-        for (int c = 0; c < CH; ++c) store_stream<u64, 2>(commit + base + (u64)c * BLOCK * 2, res[c]);
+        for (int c = 0; c < CH; ++c) store_stream<u64, 2>(commit + base + (u64)c * BLOCK * 2, nxt[c]);
         emit_changed<CH, BLOCK>(ch, grp, val, stage, counts);
     } else {
 #pragma unroll
@@ -213,10 +254,10 @@ __device__ __forceinline__ void finish_tile(const Vec<u64, 2> (&res)[CH], u64 ba
 // ---------------------------------------------------------------------------
 // K1 — ProgressTracker.Committed, uniform non-joint config of V voters.
 // ---------------------------------------------------------------------------
-template <int V, bool CHANGED>
+template <int V, int MODE>
 __global__ __launch_bounds__(kCommitBlock) void k_commit_uniform(const u64* __restrict__ match,
                                                                  u64 stride, u64 G,
-                                                                 u64* __restrict__ commit,
+                                                                 u64* __restrict__ commit, LogBounds lb,
                                                                  Pair* __restrict__ stage,
                                                                  u32* __restrict__ counts) {
     const u64 base = (u64)blockIdx.x * kTileGroups + threadIdx.x * 2;
@@ -236,19 +277,19 @@ __global__ __launch_bounds__(kCommitBlock) void k_commit_uniform(const u64* __re
             for (int s = 0; s < V; ++s) a[s] = in[c][s].v[j];
             res[c].v[j] = committed_fixed<V>(a);
         }
-    finish_tile<kCH, kCommitBlock, CHANGED>(res, base, G, commit, stage, counts);
+    finish_tile<kCH, kCommitBlock, MODE>(res, base, G, commit, lb, stage, counts);
 }
 
 // ---------------------------------------------------------------------------
 // K2 — ProgressTracker.Committed with per-group joint configs, S <= 8 slots:
 // min(CommittedIndex(incoming), CommittedIndex(outgoing)), quorum/joint.go:49-56.
 // ---------------------------------------------------------------------------
-template <int S, bool CHANGED>
+template <int S, int MODE>
 __global__ __launch_bounds__(kCommitBlock) void k_commit_masked(const u64* __restrict__ match,
                                                                 u64 stride, u64 G,
                                                                 const uint8_t* __restrict__ in_mask,
                                                                 const uint8_t* __restrict__ out_mask,
-                                                                u64* __restrict__ commit,
+                                                                u64* __restrict__ commit, LogBounds lb,
                                                                 Pair* __restrict__ stage,
                                                                 u32* __restrict__ counts) {
     const u64 base = (u64)blockIdx.x * kTileGroups + threadIdx.x * 2;
@@ -283,7 +324,7 @@ __global__ __launch_bounds__(kCommitBlock) void k_commit_masked(const u64* __res
             }
             res[c].v[j] = r;
         }
-    finish_tile<kCH, kCommitBlock, CHANGED>(res, base, G, commit, stage, counts);
+    finish_tile<kCH, kCommitBlock, MODE>(res, base, G, commit, lb, stage, counts);
 }
 
 // ---------------------------------------------------------------------------
@@ -349,12 +390,12 @@ __device__ __forceinline__ u64 wide_half(u64 val, u64 mask, int sl, int seg_base
 
 constexpr int kTileStride = 65;  // u64 per LDS tile row: 64 groups + 1 pad (bank spread)
 
-template <int W, typename MaskT, bool CHANGED>
+template <int W, typename MaskT, int MODE>
 __global__ __launch_bounds__(kBlock) void k_commit_wide(const u64* __restrict__ match, u64 stride,
                                                         u64 G, int S, const MaskT* __restrict__ in_mask,
                                                         const MaskT* __restrict__ out_mask,
                                                         int uniform_voters, u64* __restrict__ commit,
-                                                        Pair* __restrict__ stage,
+                                                        LogBounds lb, Pair* __restrict__ stage,
                                                         u32* __restrict__ counts) {
     extern __shared__ u64 lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -398,12 +439,18 @@ __global__ __launch_bounds__(kBlock) void k_commit_wide(const u64* __restrict__ 
                        (u64)(u32)__shfl((int)(u32)r, owner_seg, 64);
         if (lane / GPI == it) res = rr;
     }
-    if constexpr (CHANGED) {
+    if constexpr (MODE != kStore) {
         // ordered in-block compaction, one group per lane (block = 4 waves)
         __shared__ u32 wave_tot[kBlock / 64];
         const u64 old = commit[g];
-        const bool chg = (g < G) && (old != res);
-        commit[g] = res;
+        bool chg;
+        if constexpr (MODE == kAdvance) {
+            chg = (g < G) && (res > old) && (res >= lb.term_start[g]) && (res <= lb.last_index[g]);
+            if (chg) commit[g] = res;
+        } else {
+            chg = (g < G) && (old != res);
+            commit[g] = res;
+        }
         const u64 b = __ballot(chg);
         if (lane == 0) wave_tot[wave] = __popcll(b);
         __syncthreads();
@@ -481,6 +528,85 @@ __global__ __launch_bounds__(kBlock) void k_scatter_acks(u64* __restrict__ match
     }
     const u64 b = __ballot(bad);
     if (b != 0 && (threadIdx.x & 63) == 0) atomicAdd(rejected, (u64)__popcll(b));
+}
+
+// ---------------------------------------------------------------------------
+// K7 — the leader's per-message bookkeeping for a stream of responses that the
+// host has resolved to (group, slot): stepLeader, raft.go:1327-1561.
+//   MsgAppResp        RecentActive = true (:1337); if !Reject: MaybeUpdate(Index) (:1477)
+//   MsgHeartbeatResp  RecentActive = true (:1528); with the pending ReadIndex
+//                     context: readOnly.recvAck, acks[from] = true (read_only.go:68-76)
+//   kMsgAppended      local: raise the group's term_last to the leader's new last index
+// Every update is a max or an or — commutative and idempotent — so the batch
+// equals stepping the messages one by one in any order.  Records with no
+// Progress behind them (group >= G, slot >= S) are dropped and counted
+// (raft.go:1327-1331); other message types are counted as ignored.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void or_slot_bit(void* plane, int mbytes, u64 g, u32 slot) {
+    if (mbytes == 8) {
+        atomicOr(reinterpret_cast<u64*>(plane) + g, 1ull << slot);
+    } else {
+        const u64 byte = g * (u64)mbytes;  // little-endian: bit `slot` of the mask at this byte offset
+        atomicOr(reinterpret_cast<u32*>(plane) + (byte >> 2), 1u << (((u32)byte & 3u) * 8u + slot));
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_ingest_msgs(u64* __restrict__ match, u64 stride, u64 G, u32 S,
+                                                        void* __restrict__ active, void* __restrict__ acks,
+                                                        int mbytes, u64* __restrict__ term_last,
+                                                        const Msg* __restrict__ msgs, u64 n,
+                                                        u64* __restrict__ dropped /* [0] no Progress, [1] ignored type */) {
+    const u64 i = (u64)blockIdx.x * kBlock + threadIdx.x;
+    bool bad = false, ign = false;
+    if (i < n) {
+        const Vec<u64, 2> raw = load_vec<u64, 2>(reinterpret_cast<const u64*>(msgs + i));
+        const u32 group = (u32)raw.v[0];
+        const u32 slot = (u32)(raw.v[0] >> 32) & 0xFFu, type = (u32)(raw.v[0] >> 40) & 0xFFu;
+        const bool reject = ((raw.v[0] >> 48) & 0xFFu) != 0;
+        const u32 flags = (u32)(raw.v[0] >> 56);
+        const u64 index = raw.v[1];
+        if (type == kMsgAppended) {
+            if ((u64)group < G) {
+                if (term_last) atomicMax(term_last + group, index);
+            } else {
+                bad = true;
+            }
+        } else if (type != kMsgAppResp && type != kMsgHeartbeatResp) {
+            ign = true;
+        } else if ((u64)group >= G || slot >= S) {
+            bad = true;
+        } else {
+            or_slot_bit(active, mbytes, group, slot);
+            if (type == kMsgAppResp) {
+                if (!reject) atomicMax(match + (u64)slot * stride + group, index);
+            } else if (flags & kMsgFlagCtx) {
+                or_slot_bit(acks, mbytes, group, slot);
+            }
+        }
+    }
+    const u64 b = __ballot(bad), c = __ballot(ign);
+    if ((threadIdx.x & 63) == 0) {
+        if (b) atomicAdd(dropped, (u64)__popcll(b));
+        if (c) atomicAdd(dropped + 1, (u64)__popcll(c));
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K6 — the commit index a heartbeat may carry to each peer:
+// min(Progress.Match, raftLog.committed), sendHeartbeat raft.go:669-685.
+// Elementwise over the [slot][group] planes, 16 B per lane per access.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_heartbeat_commit(const u64* __restrict__ match, u64 stride,
+                                                             const u64* __restrict__ commit,
+                                                             u64* __restrict__ out, u32 S) {
+    const u64 g0 = ((u64)blockIdx.x * kBlock + threadIdx.x) * 2;  // < stride (multiple of 4096)
+    const Vec<u64, 2> c = load_stream<u64, 2>(commit + g0);
+    for (u32 s = 0; s < S; ++s) {
+        Vec<u64, 2> m = load_stream<u64, 2>(match + (u64)s * stride + g0);
+        m.v[0] = m.v[0] < c.v[0] ? m.v[0] : c.v[0];
+        m.v[1] = m.v[1] < c.v[1] ? m.v[1] : c.v[1];
+        store_stream<u64, 2>(out + (u64)s * stride + g0, m);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -578,11 +704,14 @@ __global__ __launch_bounds__(kBlock) void k_tally_votes_small(
 //  - QuorumActive: every non-learner row votes its RecentActive bit, so a voter
 //    is never "missing": a half is Won iff yes >= q, else Lost.
 //  - Acks: the map only ever holds true, so a half is Won or Pending.
+//  - keep != NULL (MsgCheckQuorum, raft.go:1238-1242): after the tally every
+//    RecentActive bit except the leader's own (keep = self-slot mask) is cleared
+//    "in preparation for the next CheckQuorum".
 template <bool ACKS>
 __global__ __launch_bounds__(kBlock) void k_tally_bits_small(
-    const uint8_t* __restrict__ bits, const uint8_t* __restrict__ in_mask,
+    uint8_t* __restrict__ bits, const uint8_t* __restrict__ in_mask,
     const uint8_t* __restrict__ out_mask, const uint8_t* __restrict__ learner_mask, u32 S,
-    u32 uniform_voters, uint8_t* __restrict__ out) {
+    u32 uniform_voters, uint8_t* __restrict__ out, const uint8_t* __restrict__ keep) {
     const u64 g0 = ((u64)blockIdx.x * kBlock + threadIdx.x) * 16;
     const Vec<u32, 4> B = load_stream<u32, 4>(reinterpret_cast<const u32*>(bits + g0));
     Vec<u32, 4> M0, M1, ML;
@@ -617,6 +746,13 @@ __global__ __launch_bounds__(kBlock) void k_tally_bits_small(
         }
     }
     store_stream<u32, 4>(reinterpret_cast<u32*>(out + g0), res);
+    if (keep) {
+        const Vec<u32, 4> K = load_stream<u32, 4>(reinterpret_cast<const u32*>(keep + g0));
+        Vec<u32, 4> nb;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) nb.v[w] = B.v[w] & K.v[w];
+        store_vec<u32, 4>(reinterpret_cast<u32*>(bits + g0), nb);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -668,9 +804,9 @@ __global__ __launch_bounds__(kBlock) void k_tally_votes_wide(
 
 template <typename MaskT, bool ACKS>
 __global__ __launch_bounds__(kBlock) void k_tally_bits_wide(
-    const MaskT* __restrict__ bits, u64 G, int S, const MaskT* __restrict__ in_mask,
+    MaskT* __restrict__ bits, u64 G, int S, const MaskT* __restrict__ in_mask,
     const MaskT* __restrict__ out_mask, const MaskT* __restrict__ learner_mask, int uniform_voters,
-    uint8_t* __restrict__ out) {
+    uint8_t* __restrict__ out, const MaskT* __restrict__ keep) {
     const u64 g = (u64)blockIdx.x * kBlock + threadIdx.x;
     if (g >= G) return;
     const u64 slots = S >= 64 ? kU64Max : ((1ull << S) - 1ull);
@@ -686,6 +822,7 @@ __global__ __launch_bounds__(kBlock) void k_tally_bits_wide(
     const u64 no = ACKS ? 0ull : ~yes;
     const int r = vote_joint(vote_half(m0, yes, no), vote_half(m1, yes, no));
     out[g] = ACKS ? (uint8_t)r : (uint8_t)(r == 3);
+    if (keep) bits[g] = bits[g] & keep[g];
 }
 
 }  // namespace rafthip

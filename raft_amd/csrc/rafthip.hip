@@ -15,6 +15,10 @@ using namespace rafthip;
 
 static_assert(sizeof(Pair) == sizeof(rafthip_commit_pair), "pair layout");
 static_assert(sizeof(Ack) == sizeof(rafthip_ack), "ack layout");
+static_assert(sizeof(Msg) == sizeof(rafthip_msg) && sizeof(Msg) == 16, "msg layout");
+static_assert(kMsgAppResp == RAFTHIP_MSG_APP_RESP && kMsgHeartbeatResp == RAFTHIP_MSG_HEARTBEAT_RESP &&
+                  kMsgAppended == RAFTHIP_MSG_APPENDED && kMsgFlagCtx == RAFTHIP_MSGF_READ_CTX,
+              "msg constants");
 
 namespace {
 
@@ -65,6 +69,10 @@ struct rafthip_engine {
     uint8_t* votes = nullptr;
     void* active = nullptr;
     void* acks = nullptr;
+    void* self_mask = nullptr;
+    u64* term_first = nullptr;  // raftLog entries carrying the leader's term: [term_first, term_last]
+    u64* term_last = nullptr;
+    u64* hb_commit = nullptr;   // [S][stride], min(Match, committed)
 
     // outputs
     uint8_t* vote_result = nullptr;
@@ -81,10 +89,10 @@ struct rafthip_engine {
     u32 counts_cap = 0;
 
     // scatter
-    Ack* ack_buf = nullptr;
+    Ack* ack_buf = nullptr;  // staging for host-resident ack / msg records (both 16 B)
     u64 ack_cap = 0;
-    u64* d_rejected = nullptr;
-    u64* h_scalar = nullptr;  // pinned, 2 x u64
+    u64* d_rejected = nullptr;  // [0] acks without Progress, [1] msgs without Progress, [2] msgs of other types
+    u64* h_scalar = nullptr;    // pinned, 4 x u64
 
     rafthip_stats_t stats{};
 };
@@ -141,10 +149,12 @@ int copy_rows(rafthip_engine* e, void* dst, u64 dst_stride_b, const void* src, u
 // ---- kernel dispatch -----------------------------------------------------
 
 
-template <bool CHANGED>
+template <int MODE>
 int launch_commit(rafthip_engine* e, u32* block_groups) {
+    constexpr bool CHANGED = MODE != kStore;  // needs the stage / counts buffers
     const u64 G = e->G;
     hipStream_t st = e->stream;
+    const LogBounds lb{e->term_first, e->term_last};
     if (e->uniform && e->uniform_voters == 0) {
         // Both halves empty: MaxUint64 for every group (majority.go:128-132).
         // Expressed through the masked kernel with all-zero masks.
@@ -160,8 +170,8 @@ int launch_commit(rafthip_engine* e, u32* block_groups) {
             switch (e->uniform_voters) {
 #define RAFTHIP_CASE_U(V)                                                                          \
     case V:                                                                                        \
-        hipLaunchKernelGGL((k_commit_uniform<V, CHANGED>), dim3(blocks), dim3(kCommitBlock), 0, st,   \
-                           e->match, e->stride, G, e->commit, e->stage, e->counts);                \
+        hipLaunchKernelGGL((k_commit_uniform<V, MODE>), dim3(blocks), dim3(kCommitBlock), 0, st,      \
+                           e->match, e->stride, G, e->commit, lb, e->stage, e->counts);            \
         break;
                 RAFTHIP_CASE_U(1) RAFTHIP_CASE_U(2) RAFTHIP_CASE_U(3) RAFTHIP_CASE_U(4)
                 RAFTHIP_CASE_U(5) RAFTHIP_CASE_U(6) RAFTHIP_CASE_U(7) RAFTHIP_CASE_U(8)
@@ -174,8 +184,8 @@ int launch_commit(rafthip_engine* e, u32* block_groups) {
             switch (e->S) {
 #define RAFTHIP_CASE_M(SS)                                                                         \
     case SS:                                                                                       \
-        hipLaunchKernelGGL((k_commit_masked<SS, CHANGED>), dim3(blocks), dim3(kCommitBlock), 0, st,   \
-                           e->match, e->stride, G, m0, m1, e->commit, e->stage, e->counts);        \
+        hipLaunchKernelGGL((k_commit_masked<SS, MODE>), dim3(blocks), dim3(kCommitBlock), 0, st,      \
+                           e->match, e->stride, G, m0, m1, e->commit, lb, e->stage, e->counts);    \
         break;
                 RAFTHIP_CASE_M(1) RAFTHIP_CASE_M(2) RAFTHIP_CASE_M(3) RAFTHIP_CASE_M(4)
                 RAFTHIP_CASE_M(5) RAFTHIP_CASE_M(6) RAFTHIP_CASE_M(7) RAFTHIP_CASE_M(8)
@@ -190,10 +200,10 @@ int launch_commit(rafthip_engine* e, u32* block_groups) {
         const size_t lds = (size_t)(kBlock / 64) * e->S * kTileStride * sizeof(u64);
         const int uv = uni ? (int)e->uniform_voters : 0;
 #define RAFTHIP_WIDE(W, MT)                                                                        \
-    hipLaunchKernelGGL((k_commit_wide<W, MT, CHANGED>), dim3(blocks), dim3(kBlock), lds, st,       \
+    hipLaunchKernelGGL((k_commit_wide<W, MT, MODE>), dim3(blocks), dim3(kBlock), lds, st,          \
                        e->match, e->stride, G, (int)e->S,                                          \
                        uni ? nullptr : static_cast<const MT*>(e->in_mask),                         \
-                       uni ? nullptr : static_cast<const MT*>(e->out_mask), uv, e->commit,         \
+                       uni ? nullptr : static_cast<const MT*>(e->out_mask), uv, e->commit, lb,     \
                        e->stage, e->counts)
         if (e->S <= 16) {
             RAFTHIP_WIDE(16, uint16_t);
@@ -244,7 +254,7 @@ static int read_u8(rafthip_engine* e, const uint8_t* plane, const char* what, ui
 }
 
 template <bool ACKS>
-static int tally_bits(rafthip_engine* e, void* bits, uint8_t*& out, const char* what) {
+static int tally_bits(rafthip_engine* e, void* bits, uint8_t*& out, const char* what, const void* keep = nullptr) {
     if (!bits) return fail(RAFTHIP_EINVAL, "%s bits have not been uploaded", what);
     int rc;
     if ((rc = ensure(e, out, e->stride))) return rc;
@@ -254,20 +264,20 @@ static int tally_bits(rafthip_engine* e, void* bits, uint8_t*& out, const char* 
     if (e->S <= 8) {
         const u32 blocks = (u32)((e->G + (u64)kBlock * 16 - 1) / ((u64)kBlock * 16));
         hipLaunchKernelGGL((k_tally_bits_small<ACKS>), dim3(blocks), dim3(kBlock), 0, st,
-                           static_cast<const uint8_t*>(bits),
+                           static_cast<uint8_t*>(bits),
                            uni ? nullptr : static_cast<const uint8_t*>(e->in_mask),
                            uni ? nullptr : static_cast<const uint8_t*>(e->out_mask),
                            uni ? nullptr : static_cast<const uint8_t*>(e->learner_mask), e->S,
-                           e->uniform_voters, out);
+                           e->uniform_voters, out, static_cast<const uint8_t*>(keep));
     } else {
         const u32 blocks = (u32)((e->G + kBlock - 1) / kBlock);
 #define RAFTHIP_BW(MT)                                                                              \
     hipLaunchKernelGGL((k_tally_bits_wide<MT, ACKS>), dim3(blocks), dim3(kBlock), 0, st,            \
-                       static_cast<const MT*>(bits), e->G, (int)e->S,                               \
+                       static_cast<MT*>(bits), e->G, (int)e->S,                                     \
                        uni ? nullptr : static_cast<const MT*>(e->in_mask),                          \
                        uni ? nullptr : static_cast<const MT*>(e->out_mask),                         \
                        uni ? nullptr : static_cast<const MT*>(e->learner_mask),                     \
-                       (int)e->uniform_voters, out)
+                       (int)e->uniform_voters, out, static_cast<const MT*>(keep))
         if (e->mbytes == 2) {
             RAFTHIP_BW(uint16_t);
         } else if (e->mbytes == 4) {
@@ -313,6 +323,73 @@ static int oneshot_engine(int device, uint64_t G, uint32_t S, const void* in_mas
         return rc;
     }
     *out = e;
+    return RAFTHIP_OK;
+}
+
+// 16-byte records (acks or msgs) -> a device pointer; host memory is staged
+// through the engine's record buffer.
+static int stage_records(rafthip_engine* e, const void* recs, uint64_t n, const void** d_recs, bool* staged) {
+    hipPointerAttribute_t attr;
+    *staged = false;
+    if (hipPointerGetAttributes(&attr, recs) == hipSuccess && attr.type == hipMemoryTypeDevice) {
+        *d_recs = recs;
+        return RAFTHIP_OK;
+    }
+    (void)hipGetLastError();  // plain host memory reports an error on some runtimes
+    if (e->ack_cap < n) {
+        if (e->ack_buf) {
+            HIP_TRY(hipStreamSynchronize(e->stream));
+            HIP_TRY(hipFree(e->ack_buf));
+            e->ack_buf = nullptr;
+            e->ack_cap = 0;
+        }
+        void* q = nullptr;
+        HIP_TRY(hipMalloc(&q, n * sizeof(Ack)));
+        e->ack_buf = static_cast<Ack*>(q);
+        e->ack_cap = n;
+    }
+    HIP_TRY(hipMemcpyAsync(e->ack_buf, recs, n * sizeof(Ack), hipMemcpyHostToDevice, e->stream));
+    *d_recs = e->ack_buf;
+    *staged = true;
+    e->stats.bytes_uploaded += n * sizeof(Ack);
+    return RAFTHIP_OK;
+}
+
+// Commit pass that reports pairs (MODE kChanged / kAdvance): launch, scan the
+// per-tile counts, pack the ordered runs, hand back the total and the pairs.
+template <int MODE>
+static int commit_report(rafthip_engine* e, rafthip_commit_pair* dst, uint64_t max_pairs, uint64_t* n_out) {
+    if (!e || !n_out) return fail(RAFTHIP_EINVAL, "engine/count pointer is NULL");
+    if (max_pairs > 0 && !dst) return fail(RAFTHIP_EINVAL, "dst is NULL with max_pairs > 0");
+    DeviceGuard guard(e->device);
+    int rc = ensure_changed_buffers(e);
+    if (rc) return rc;
+    if (MODE == kAdvance) {
+        if ((rc = ensure(e, e->term_first, (size_t)e->stride * sizeof(u64)))) return rc;
+        if ((rc = ensure(e, e->term_last, (size_t)e->stride * sizeof(u64)))) return rc;
+    }
+    u32 bg = 0;
+    if ((rc = launch_commit<MODE>(e, &bg))) return rc;
+    const u32 blocks = (u32)((e->G + bg - 1) / bg);
+    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, e->stream, e->counts, blocks, e->offsets);
+    hipLaunchKernelGGL(k_pack_pairs, dim3(blocks), dim3(kBlock), 0, e->stream, e->stage, e->counts,
+                       e->offsets, bg, e->packed);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(e->h_scalar + 1, e->offsets + blocks, sizeof(u64), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    const u64 total = e->h_scalar[1];
+    *n_out = total;
+    const u64 ncopy = total < max_pairs ? total : max_pairs;
+    if (ncopy) {
+        HIP_TRY(hipMemcpyAsync(dst, e->packed, ncopy * sizeof(Pair), hipMemcpyDefault, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        e->stats.bytes_downloaded += ncopy * sizeof(Pair);
+    }
+    if (MODE == kAdvance) {
+        e->stats.advanced_reported += total;
+    } else {
+        e->stats.changed_reported += total;
+    }
     return RAFTHIP_OK;
 }
 
@@ -386,8 +463,8 @@ int rafthip_create(const rafthip_config* cfg, rafthip_engine** out) {
         }
         if ((rc = ensure(e, e->match, (size_t)e->S * e->stride * sizeof(u64)))) break;
         if ((rc = ensure(e, e->commit, (size_t)e->stride * sizeof(u64)))) break;
-        if ((rc = ensure(e, e->d_rejected, sizeof(u64)))) break;
-        hipError_t err = hipHostMalloc(reinterpret_cast<void**>(&e->h_scalar), 2 * sizeof(u64), hipHostMallocDefault);
+        if ((rc = ensure(e, e->d_rejected, 4 * sizeof(u64)))) break;
+        hipError_t err = hipHostMalloc(reinterpret_cast<void**>(&e->h_scalar), 4 * sizeof(u64), hipHostMallocDefault);
         if (err != hipSuccess) {
             rc = fail(RAFTHIP_ENOMEM, "hipHostMalloc: %s", hipGetErrorString(err));
             break;
@@ -413,7 +490,7 @@ int rafthip_destroy(rafthip_engine* e) {
     void* bufs[] = {e->in_mask, e->out_mask,   e->learner_mask, e->match,    e->commit, e->votes,
                     e->active,  e->acks,       e->vote_result,  e->granted,  e->rejected, e->qactive,
                     e->ack_result, e->stage,   e->packed,       e->counts,   e->offsets,  e->ack_buf,
-                    e->d_rejected};
+                    e->d_rejected, e->self_mask, e->term_first, e->term_last, e->hb_commit};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (e->h_scalar) (void)hipHostFree(e->h_scalar);
@@ -433,9 +510,12 @@ int rafthip_mask_bytes(const rafthip_engine* e) { return e ? e->mbytes : RAFTHIP
 int rafthip_stats(rafthip_engine* e, rafthip_stats_t* out) {
     if (!e || !out) return fail(RAFTHIP_EINVAL, "engine/out is NULL");
     DeviceGuard guard(e->device);
-    HIP_TRY(hipMemcpyAsync(e->h_scalar, e->d_rejected, sizeof(u64), hipMemcpyDeviceToHost, e->stream));
+    u64 host[3] = {0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(host, e->d_rejected, sizeof(host), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
-    e->stats.acks_rejected = e->h_scalar[0];
+    e->stats.acks_rejected = host[0];
+    e->stats.msgs_dropped = host[1];
+    e->stats.msgs_ignored = host[2];
     *out = e->stats;
     return RAFTHIP_OK;
 }
@@ -601,36 +681,41 @@ int rafthip_scatter_acks(rafthip_engine* e, const rafthip_ack* recs, uint64_t n)
     if (!recs) return fail(RAFTHIP_EINVAL, "recs is NULL");
     if (n > 0xFFFFFFFFull * kBlock) return fail(RAFTHIP_EINVAL, "too many acks in one call");
     DeviceGuard guard(e->device);
-    hipPointerAttribute_t attr;
-    const Ack* d_recs = nullptr;
+    const void* d_recs = nullptr;
     bool staged = false;
-    if (hipPointerGetAttributes(&attr, recs) == hipSuccess && attr.type == hipMemoryTypeDevice) {
-        d_recs = reinterpret_cast<const Ack*>(recs);
-    } else {
-        (void)hipGetLastError();  // plain host memory reports an error on some runtimes
-        if (e->ack_cap < n) {
-            if (e->ack_buf) {
-                HIP_TRY(hipStreamSynchronize(e->stream));
-                HIP_TRY(hipFree(e->ack_buf));
-                e->ack_buf = nullptr;
-                e->ack_cap = 0;
-            }
-            void* q = nullptr;
-            HIP_TRY(hipMalloc(&q, n * sizeof(Ack)));
-            e->ack_buf = static_cast<Ack*>(q);
-            e->ack_cap = n;
-        }
-        HIP_TRY(hipMemcpyAsync(e->ack_buf, recs, n * sizeof(Ack), hipMemcpyHostToDevice, e->stream));
-        d_recs = e->ack_buf;
-        staged = true;
-        e->stats.bytes_uploaded += n * sizeof(Ack);
-    }
+    int rc = stage_records(e, recs, n, &d_recs, &staged);
+    if (rc) return rc;
     const u32 blocks = (u32)((n + kBlock - 1) / kBlock);
     hipLaunchKernelGGL(k_scatter_acks, dim3(blocks), dim3(kBlock), 0, e->stream, e->match, e->stride, e->G,
-                       e->S, d_recs, (u64)n, e->d_rejected);
+                       e->S, static_cast<const Ack*>(d_recs), (u64)n, e->d_rejected);
     HIP_TRY(hipGetLastError());
     if (staged) HIP_TRY(hipStreamSynchronize(e->stream));  // caller may reuse its host buffer
     e->stats.acks_applied += n;
+    return RAFTHIP_OK;
+}
+
+int rafthip_ingest_msgs(rafthip_engine* e, const rafthip_msg* msgs, uint64_t n) {
+    if (!e) return fail(RAFTHIP_EINVAL, "engine is NULL");
+    if (n == 0) return RAFTHIP_OK;
+    if (!msgs) return fail(RAFTHIP_EINVAL, "msgs is NULL");
+    if (n > 0xFFFFFFFFull * kBlock) return fail(RAFTHIP_EINVAL, "too many messages in one call");
+    DeviceGuard guard(e->device);
+    int rc;
+    const size_t mb = (size_t)e->stride * e->mbytes;
+    if ((rc = ensure(e, e->active, mb))) return rc;
+    if ((rc = ensure(e, e->acks, mb))) return rc;
+    if ((rc = ensure(e, e->term_last, (size_t)e->stride * sizeof(u64)))) return rc;
+    if ((rc = ensure(e, e->term_first, (size_t)e->stride * sizeof(u64)))) return rc;
+    const void* d_recs = nullptr;
+    bool staged = false;
+    if ((rc = stage_records(e, msgs, n, &d_recs, &staged))) return rc;
+    const u32 blocks = (u32)((n + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(k_ingest_msgs, dim3(blocks), dim3(kBlock), 0, e->stream, e->match, e->stride, e->G,
+                       e->S, e->active, e->acks, e->mbytes, e->term_last, static_cast<const Msg*>(d_recs),
+                       (u64)n, e->d_rejected + 1);
+    HIP_TRY(hipGetLastError());
+    if (staged) HIP_TRY(hipStreamSynchronize(e->stream));
+    e->stats.msgs_ingested += n;
     return RAFTHIP_OK;
 }
 
@@ -638,34 +723,65 @@ int rafthip_commit(rafthip_engine* e) {
     if (!e) return fail(RAFTHIP_EINVAL, "engine is NULL");
     DeviceGuard guard(e->device);
     u32 bg = 0;
-    return launch_commit<false>(e, &bg);
+    return launch_commit<kStore>(e, &bg);
 }
 
 int rafthip_commit_changed(rafthip_engine* e, rafthip_commit_pair* dst, uint64_t max_pairs,
                            uint64_t* n_changed) {
-    if (!e || !n_changed) return fail(RAFTHIP_EINVAL, "engine/n_changed is NULL");
-    if (max_pairs > 0 && !dst) return fail(RAFTHIP_EINVAL, "dst is NULL with max_pairs > 0");
-    DeviceGuard guard(e->device);
-    int rc = ensure_changed_buffers(e);
+    return commit_report<kChanged>(e, dst, max_pairs, n_changed);
+}
+
+int rafthip_commit_advance(rafthip_engine* e, rafthip_commit_pair* dst, uint64_t max_pairs,
+                           uint64_t* n_advanced) {
+    return commit_report<kAdvance>(e, dst, max_pairs, n_advanced);
+}
+
+int rafthip_upload_term_range(rafthip_engine* e, uint64_t first, uint64_t count, const uint64_t* term_first,
+                              const uint64_t* term_last) {
+    int rc = check_range(e, first, count);
     if (rc) return rc;
-    u32 bg = 0;
-    if ((rc = launch_commit<true>(e, &bg))) return rc;
-    const u32 blocks = (u32)((e->G + bg - 1) / bg);
-    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, e->stream, e->counts, blocks, e->offsets);
-    hipLaunchKernelGGL(k_pack_pairs, dim3(blocks), dim3(kBlock), 0, e->stream, e->stage, e->counts,
-                       e->offsets, bg, e->packed);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(e->h_scalar + 1, e->offsets + blocks, sizeof(u64), hipMemcpyDeviceToHost, e->stream));
+    if (!term_first || !term_last) return fail(RAFTHIP_EINVAL, "term_first/term_last is NULL");
+    DeviceGuard guard(e->device);
+    if ((rc = ensure(e, e->term_first, (size_t)e->stride * sizeof(u64)))) return rc;
+    if ((rc = ensure(e, e->term_last, (size_t)e->stride * sizeof(u64)))) return rc;
+    HIP_TRY(hipMemcpyAsync(e->term_first + first, term_first, count * 8, hipMemcpyDefault, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->term_last + first, term_last, count * 8, hipMemcpyDefault, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
-    const u64 total = e->h_scalar[1];
-    *n_changed = total;
-    const u64 ncopy = total < max_pairs ? total : max_pairs;
-    if (ncopy) {
-        HIP_TRY(hipMemcpyAsync(dst, e->packed, ncopy * sizeof(Pair), hipMemcpyDefault, e->stream));
-        HIP_TRY(hipStreamSynchronize(e->stream));
-        e->stats.bytes_downloaded += ncopy * sizeof(Pair);
-    }
-    e->stats.changed_reported += total;
+    e->stats.bytes_uploaded += count * 16;
+    return RAFTHIP_OK;
+}
+
+int rafthip_read_term_range(rafthip_engine* e, uint64_t first, uint64_t count, uint64_t* term_first,
+                            uint64_t* term_last) {
+    int rc = check_range(e, first, count);
+    if (rc) return rc;
+    if (!term_first && !term_last) return fail(RAFTHIP_EINVAL, "term_first and term_last are both NULL");
+    if (!e->term_first || !e->term_last) return fail(RAFTHIP_EINVAL, "no term range has been uploaded yet");
+    DeviceGuard guard(e->device);
+    if (term_first) HIP_TRY(hipMemcpyAsync(term_first, e->term_first + first, count * 8, hipMemcpyDefault, e->stream));
+    if (term_last) HIP_TRY(hipMemcpyAsync(term_last, e->term_last + first, count * 8, hipMemcpyDefault, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    e->stats.bytes_downloaded += count * 8 * ((term_first ? 1 : 0) + (term_last ? 1 : 0));
+    return RAFTHIP_OK;
+}
+
+int rafthip_heartbeat_commit(rafthip_engine* e, uint64_t first, uint64_t count, uint64_t* dst,
+                             uint64_t dst_stride) {
+    int rc = check_range(e, first, count);
+    if (rc) return rc;
+    if (dst && dst_stride < count)
+        return fail(RAFTHIP_EINVAL, "dst_stride %llu < count %llu", (u64)dst_stride, (u64)count);
+    DeviceGuard guard(e->device);
+    if ((rc = ensure(e, e->hb_commit, (size_t)e->S * e->stride * sizeof(u64)))) return rc;
+    const u32 blocks = (u32)(e->stride / ((u64)kBlock * 2));  // stride is a multiple of 4096
+    hipLaunchKernelGGL(k_heartbeat_commit, dim3(blocks), dim3(kBlock), 0, e->stream, e->match, e->stride,
+                       e->commit, e->hb_commit, e->S);
+    HIP_TRY(hipGetLastError());
+    e->stats.groups_evaluated += e->G;
+    if (!dst) return RAFTHIP_OK;  // result stays on the device: rafthip_plane(RAFTHIP_PLANE_HEARTBEAT)
+    if ((rc = copy_rows(e, dst, dst_stride * 8, e->hb_commit + first, e->stride * 8, count * 8, e->S))) return rc;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    e->stats.bytes_downloaded += count * 8 * e->S;
     return RAFTHIP_OK;
 }
 
@@ -748,6 +864,45 @@ int rafthip_quorum_active(rafthip_engine* e) {
     return tally_bits<false>(e, e->active, e->qactive, "RecentActive");
 }
 
+int rafthip_upload_self(rafthip_engine* e, uint64_t first, uint64_t count, const void* src) {
+    if (!e) return fail(RAFTHIP_EINVAL, "engine is NULL");
+    return upload_bits(e, e->self_mask, first, count, src);
+}
+
+int rafthip_check_quorum(rafthip_engine* e) {
+    if (!e) return fail(RAFTHIP_EINVAL, "engine is NULL");
+    DeviceGuard guard(e->device);
+    int rc;
+    // groups whose self mask was never uploaded keep no bit: every RecentActive is cleared
+    if ((rc = ensure(e, e->self_mask, (size_t)e->stride * e->mbytes))) return rc;
+    return tally_bits<false>(e, e->active, e->qactive, "RecentActive", e->self_mask);
+}
+
+static int read_bits(rafthip_engine* e, const void* plane, const char* what, uint64_t first, uint64_t count,
+                     void* dst) {
+    int rc = check_range(e, first, count);
+    if (rc) return rc;
+    if (!dst) return fail(RAFTHIP_EINVAL, "dst is NULL");
+    if (!plane) return fail(RAFTHIP_EINVAL, "%s bits do not exist yet", what);
+    DeviceGuard guard(e->device);
+    const size_t mb = (size_t)e->mbytes;
+    HIP_TRY(hipMemcpyAsync(dst, static_cast<const char*>(plane) + first * mb, count * mb, hipMemcpyDefault,
+                           e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    e->stats.bytes_downloaded += count * mb;
+    return RAFTHIP_OK;
+}
+
+int rafthip_read_active(rafthip_engine* e, uint64_t first, uint64_t count, void* dst) {
+    if (!e) return fail(RAFTHIP_EINVAL, "engine is NULL");
+    return read_bits(e, e->active, "RecentActive", first, count, dst);
+}
+
+int rafthip_read_acks(rafthip_engine* e, uint64_t first, uint64_t count, void* dst) {
+    if (!e) return fail(RAFTHIP_EINVAL, "engine is NULL");
+    return read_bits(e, e->acks, "ReadIndex ack", first, count, dst);
+}
+
 int rafthip_read_quorum_active(rafthip_engine* e, uint64_t first, uint64_t count, uint8_t* dst) {
     int rc = check_range(e, first, count);
     if (rc) return rc;
@@ -784,6 +939,10 @@ int rafthip_plane(rafthip_engine* e, int which, void** ptr, uint64_t* stride) {
         case RAFTHIP_PLANE_VOTES:
             if ((rc = ensure(e, e->votes, (size_t)e->S * e->stride))) return rc;
             *ptr = e->votes;
+            break;
+        case RAFTHIP_PLANE_HEARTBEAT:
+            if ((rc = ensure(e, e->hb_commit, (size_t)e->S * e->stride * sizeof(u64)))) return rc;
+            *ptr = e->hb_commit;
             break;
         default: return fail(RAFTHIP_EINVAL, "unknown plane %d", which);
     }

@@ -141,3 +141,38 @@ def dist_b(seed, S, G):
     alleq = (r[S + 1] % np.uint64(100)) == np.uint64(0)
     m[:, alleq] = L[alleq]
     return np.ascontiguousarray(m)
+
+
+def term_range(log_off, log_terms, log_first, log_snap_term, term):
+    """What a host hands to rafthip_upload_term_range: per group the first and
+    last log index whose entry carries `term` (log terms never decrease, so they
+    form one run; the compacted boundary entry first-1 keeps its term,
+    log.go:381-407); an empty range (1, 0) when there is none or term == 0."""
+    G = len(log_first)
+    tf = np.ones(G, dtype=np.uint64)
+    tl = np.zeros(G, dtype=np.uint64)
+    for g in range(G):
+        if int(term[g]) == 0:
+            continue
+        t = np.concatenate(([log_snap_term[g]], log_terms[int(log_off[g]):int(log_off[g + 1])]))
+        hit = np.flatnonzero(t == term[g])
+        if len(hit):
+            tf[g] = int(log_first[g]) - 1 + int(hit[0])
+            tl[g] = int(log_first[g]) - 1 + int(hit[-1])
+    return tf, tl
+
+
+def random_logs(rng, G, max_len=12):
+    """Per-group logs with non-decreasing terms, CSR-packed: (off, terms, first, snap_term)."""
+    lens = rng.integers(0, max_len + 1, size=G)
+    off = np.zeros(G + 1, dtype=np.uint64)
+    off[1:] = np.cumsum(lens)
+    first = rng.integers(1, 6, size=G).astype(np.uint64)
+    snap = rng.integers(0, 3, size=G).astype(np.uint64)
+    terms = np.zeros(int(off[-1]), dtype=np.uint64)
+    for g in range(G):
+        n = int(lens[g])
+        if n:
+            steps = (rng.random(n) < 0.3).astype(np.uint64)
+            terms[int(off[g]):int(off[g + 1])] = snap[g] + np.uint64(rng.integers(0, 2)) + np.cumsum(steps).astype(np.uint64)
+    return off, terms, first, snap
