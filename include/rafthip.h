@@ -68,12 +68,18 @@ extern "C" {
 
 typedef struct rafthip_engine rafthip_engine;
 
+/* Engines with more than 8 slots: sort each group across the lanes of a
+ * wavefront (bitonic network over DPP / ds_swizzle, LDS-staged tile) instead
+ * of the default one-group-per-lane register network.  Same results; kept
+ * selectable for A/B measurement. */
+#define RAFTHIP_FLAG_WIDE_BITONIC 1u
+
 typedef struct rafthip_config {
     uint32_t struct_size; /* sizeof(rafthip_config), for ABI growth */
     int32_t device;       /* HIP device ordinal */
     uint64_t num_groups;  /* G >= 1 */
     uint32_t num_slots;   /* S in [1, 64] */
-    uint32_t flags;       /* 0 */
+    uint32_t flags;       /* RAFTHIP_FLAG_* or 0 */
     void *stream;         /* hipStream_t to run on, or NULL: the engine makes its own */
 } rafthip_config;
 

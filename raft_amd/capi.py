@@ -18,6 +18,7 @@ MSG_DTYPE = np.dtype([("group", "<u4"), ("slot", "u1"), ("type", "u1"), ("reject
                       ("index", "<u8")])
 MSG_APP_RESP, MSG_HEARTBEAT_RESP, MSG_APPENDED, MSGF_READ_CTX = 4, 9, 0xF0, 1
 PLANE_HEARTBEAT = 3
+FLAG_WIDE_BITONIC = 1
 
 PLANE_MATCH, PLANE_COMMIT, PLANE_VOTES = 0, 1, 2
 VOTE_PENDING, VOTE_LOST, VOTE_WON = 1, 2, 3
@@ -151,10 +152,10 @@ def _ptr(a):
 class Engine:
     """One engine per GPU: G groups × S slots of device-resident state."""
 
-    def __init__(self, num_groups, num_slots, device=0, stream=None):
+    def __init__(self, num_groups, num_slots, device=0, stream=None, flags=0):
         self._h = None
         L = load_library()
-        cfg = _Config(C.sizeof(_Config), device, num_groups, num_slots, 0, stream)
+        cfg = _Config(C.sizeof(_Config), device, num_groups, num_slots, flags, stream)
         h = C.c_void_p()
         _check(L.rafthip_create(C.byref(cfg), C.byref(h)))
         self._L, self._h = L, h

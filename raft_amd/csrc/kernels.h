@@ -106,6 +106,18 @@ __device__ __forceinline__ void sort_asc(u64 (&v)[N]) {
     if constexpr (SortNet<N>::n > 0) sort_impl<N>(v, std::make_integer_sequence<int, SortNet<N>::n>{});
 }
 
+template <int N, int... K>
+__device__ __forceinline__ void batcher_impl(u64 (&v)[N], std::integer_sequence<int, K...>) {
+    (cex<Batcher<N>::list.ce[K].a, Batcher<N>::list.ce[K].b, N>(v), ...);
+}
+// Ascending sort of N keys (9..64) in registers: Batcher's odd-even merge sort.
+// (Hand-scheduled borrow-chain compare-exchanges in inline asm were tried and
+// lost to the compiler's v_cmp_u64 + v_cndmask form on MI355X, tools/cexbench.hip.)
+template <int N>
+__device__ __forceinline__ void sort_asc_batcher(u64 (&v)[N]) {
+    batcher_impl<N>(v, std::make_integer_sequence<int, Batcher<N>::n>{});
+}
+
 // MajorityConfig.CommittedIndex for a config of exactly V voters held in v[]:
 // sort, take srt[n-(n/2+1)] — quorum/majority.go:165-171.
 template <int V>
@@ -327,6 +339,119 @@ __global__ __launch_bounds__(kCommitBlock) void k_commit_masked(const u64* __res
     finish_tile<kCH, kCommitBlock, MODE>(res, base, G, commit, lb, stage, counts);
 }
 
+// Tail of the one-group-per-lane kernels (block = kBlock lanes = 4 waves):
+// store / diff / term-guard as MODE says, with the same ordered in-block
+// compaction of reported pairs as emit_changed.
+template <int MODE>
+__device__ __forceinline__ void finish_lane(u64 res, u64 g, u64 G, u64* __restrict__ commit, LogBounds lb,
+                                            Pair* __restrict__ stage, u32* __restrict__ counts) {
+    if constexpr (MODE != kStore) {
+        __shared__ u32 wave_tot[kBlock / 64];
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const u64 old = commit[g];
+        bool chg;
+        if constexpr (MODE == kAdvance) {
+            chg = (g < G) && (res > old) && (res >= lb.term_start[g]) && (res <= lb.last_index[g]);
+            if (chg) commit[g] = res;
+        } else {
+            chg = (g < G) && (old != res);
+            commit[g] = res;
+        }
+        const u64 b = __ballot(chg);
+        if (lane == 0) wave_tot[wave] = __popcll(b);
+        __syncthreads();
+        u32 pos = __popcll(b & ((1ull << lane) - 1ull)), all = 0;
+#pragma unroll
+        for (int w = 0; w < kBlock / 64; ++w) {
+            const u32 t = wave_tot[w];
+            pos += (w < wave) ? t : 0u;
+            all += t;
+        }
+        if (chg) stage[(u64)blockIdx.x * kBlock + pos] = Pair{g, res};
+        if (threadIdx.x == 0) counts[blockIdx.x] = all;
+    } else {
+        commit[g] = res;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K4r — wide voter sets (9..64 slots), one group per lane, all keys in
+// registers: the N-key Batcher network above (63 / 191 / 543 compare-exchanges
+// at N = 16 / 32 / 64) sorts the masked keys; position N-q is the q-th largest
+// member.  Every compare-exchange is done once by one lane (the cross-lane
+// bitonic network of K4 does each twice and pays a DPP / LDS-crossbar move per
+// step), loads are the same coalesced plane streams as K1, and there is no LDS
+// staging.  A joint group costs a second pass (keys re-read; first pass leaves
+// them in L2); a wave with no joint group skips it.
+// ---------------------------------------------------------------------------
+template <int N, bool NT>
+__device__ __forceinline__ u64 regs_half(const u64* __restrict__ match, u64 stride, int S, u64 m) {
+    u64 a[N];
+    // wave-uniform base + small per-lane offset: the N addresses stay in SGPRs
+    const u64* base = match + (u64)blockIdx.x * kBlock;
+    const u32 t = threadIdx.x;
+#pragma unroll
+    for (int s = 0; s < N; ++s) {
+        // rows >= S do not exist: re-read row 0 (a cache hit; m has no bit there)
+        const u64* p = base + (u64)(s < S ? s : 0) * stride;
+        // keep the row base an SGPR pair (saddr + lane-offset addressing: no VGPR
+        // pair per row), and opaque, so the joint loop re-loads instead of keeping
+        // a second copy of every key live
+        asm volatile("" : "+s"(p));
+        const u64 v = NT ? __builtin_nontemporal_load(p + t) : p[t];
+        // non-members become key 0; arithmetic mask (no per-key lane-mask SGPR pair)
+        a[s] = v & (0ull - ((m >> s) & 1ull));
+    }
+    sort_asc_batcher<N>(a);
+    const int n = __popcll(m);
+    const int pos = N - (n / 2 + 1);
+    constexpr int kLo = N - (N / 2 + 1);
+    u64 r = a[kLo];
+#pragma unroll
+    for (int i = kLo + 1; i < N; ++i) r = (pos == i) ? a[i] : r;
+    return n == 0 ? kU64Max : r;
+}
+
+// 48 / 64 keys: ask for 3 waves per SIMD (<= 168 VGPRs); left alone the
+// compiler takes 186 and drops to 2 (measured 632 -> 576 us at 2^22 x 64).
+template <int N, typename MaskT, int MODE>
+__global__ __launch_bounds__(kBlock, (N > 32 ? 3 : 1)) void k_commit_regs(const u64* __restrict__ match, u64 stride, u64 G,
+                                                        int S, const MaskT* __restrict__ in_mask,
+                                                        const MaskT* __restrict__ out_mask,
+                                                        int uniform_voters, u64* __restrict__ commit,
+                                                        LogBounds lb, Pair* __restrict__ stage,
+                                                        u32* __restrict__ counts) {
+    const u64 g = (u64)blockIdx.x * kBlock + threadIdx.x;  // < stride (stride is a multiple of 4096)
+    u64 m0, m1;
+    if (in_mask) {
+        m0 = (u64)in_mask[g];
+        m1 = (u64)out_mask[g];
+    } else {
+        m0 = uniform_voters >= 64 ? kU64Max : ((1ull << uniform_voters) - 1ull);
+        m1 = 0;
+    }
+    if (S < 64) {
+        const u64 valid = (1ull << S) - 1ull;
+        m0 &= valid;
+        m1 &= valid;
+    }
+    u64 res;
+    if (__any(m1 != 0)) {
+        // Joint wave: one rolled loop over the two halves, so the keys are loaded
+        // per half (the second read hits L2) instead of being kept twice in
+        // registers.  An empty half yields MaxUint64, the identity of min.
+        res = kU64Max;
+#pragma unroll 1
+        for (int h = 0; h < 2; ++h) {
+            const u64 r = regs_half<N, false>(match, stride, S, h ? m1 : m0);
+            res = r < res ? r : res;
+        }
+    } else {
+        res = regs_half<N, true>(match, stride, S, m0);
+    }
+    finish_lane<MODE>(res, g, G, commit, lb, stage, counts);
+}
+
 // ---------------------------------------------------------------------------
 // K4 — wide voter sets (9..64 slots).  A wavefront stages a 64-group tile of
 // every plane in LDS (coalesced reads), then turns the tile: lane = slot.
@@ -439,33 +564,7 @@ __global__ __launch_bounds__(kBlock) void k_commit_wide(const u64* __restrict__ 
                        (u64)(u32)__shfl((int)(u32)r, owner_seg, 64);
         if (lane / GPI == it) res = rr;
     }
-    if constexpr (MODE != kStore) {
-        // ordered in-block compaction, one group per lane (block = 4 waves)
-        __shared__ u32 wave_tot[kBlock / 64];
-        const u64 old = commit[g];
-        bool chg;
-        if constexpr (MODE == kAdvance) {
-            chg = (g < G) && (res > old) && (res >= lb.term_start[g]) && (res <= lb.last_index[g]);
-            if (chg) commit[g] = res;
-        } else {
-            chg = (g < G) && (old != res);
-            commit[g] = res;
-        }
-        const u64 b = __ballot(chg);
-        if (lane == 0) wave_tot[wave] = __popcll(b);
-        __syncthreads();
-        u32 pos = __popcll(b & ((1ull << lane) - 1ull)), all = 0;
-#pragma unroll
-        for (int w = 0; w < kBlock / 64; ++w) {
-            const u32 t = wave_tot[w];
-            pos += (w < wave) ? t : 0u;
-            all += t;
-        }
-        if (chg) stage[(u64)blockIdx.x * kBlock + pos] = Pair{g, res};
-        if (threadIdx.x == 0) counts[blockIdx.x] = all;
-    } else {
-        commit[g] = res;
-    }
+    finish_lane<MODE>(res, g, G, commit, lb, stage, counts);
 }
 
 // ---------------------------------------------------------------------------
@@ -542,12 +641,19 @@ __global__ __launch_bounds__(kBlock) void k_scatter_acks(u64* __restrict__ match
 // Progress behind them (group >= G, slot >= S) are dropped and counted
 // (raft.go:1327-1331); other message types are counted as ignored.
 // ---------------------------------------------------------------------------
+// The bit is read first: RecentActive / ack bits are mostly set already in
+// steady state (they are cleared once per election timeout), and a set bit
+// needs no atomic.  A stale read can only cause a redundant or.
 __device__ __forceinline__ void or_slot_bit(void* plane, int mbytes, u64 g, u32 slot) {
     if (mbytes == 8) {
-        atomicOr(reinterpret_cast<u64*>(plane) + g, 1ull << slot);
+        u64* w = reinterpret_cast<u64*>(plane) + g;
+        const u64 bit = 1ull << slot;
+        if (!(*w & bit)) atomicOr(w, bit);
     } else {
         const u64 byte = g * (u64)mbytes;  // little-endian: bit `slot` of the mask at this byte offset
-        atomicOr(reinterpret_cast<u32*>(plane) + (byte >> 2), 1u << (((u32)byte & 3u) * 8u + slot));
+        u32* w = reinterpret_cast<u32*>(plane) + (byte >> 2);
+        const u32 bit = 1u << (((u32)byte & 3u) * 8u + slot);
+        if (!(*w & bit)) atomicOr(w, bit);
     }
 }
 

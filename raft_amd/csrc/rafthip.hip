@@ -54,6 +54,7 @@ struct rafthip_engine {
     int mbytes = 1;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    bool wide_bitonic = false;  // RAFTHIP_FLAG_WIDE_BITONIC
 
     // config
     bool uniform = true;
@@ -149,6 +150,12 @@ int copy_rows(rafthip_engine* e, void* dst, u64 dst_stride_b, const void* src, u
 // ---- kernel dispatch -----------------------------------------------------
 
 
+// Lane-per-group sorting-network kernels K1 / K2 (tile = kTileGroups) vs the
+// one-group-per-lane wide kernels (tile = kBlock).
+bool small_commit_path(const rafthip_engine* e) {
+    return e->S <= 8 || (e->uniform && e->uniform_voters > 0 && e->uniform_voters <= 8);
+}
+
 template <int MODE>
 int launch_commit(rafthip_engine* e, u32* block_groups) {
     constexpr bool CHANGED = MODE != kStore;  // needs the stage / counts buffers
@@ -162,7 +169,9 @@ int launch_commit(rafthip_engine* e, u32* block_groups) {
         if (rc) return rc;
     }
     const bool uni = e->uniform && e->uniform_voters > 0;
-    if (e->S <= 8) {
+    if (small_commit_path(e)) {
+        // K1 reads only the voter planes, so a uniform config of <= 8 voters takes
+        // it whatever S is (e.g. 7 voters + 2 learner rows).
         const u32 blocks = (u32)((G + kTileGroups - 1) / kTileGroups);
         *block_groups = kTileGroups;
         if (CHANGED && blocks > e->counts_cap) return fail(RAFTHIP_EINVAL, "internal: counts capacity");
@@ -197,22 +206,45 @@ int launch_commit(rafthip_engine* e, u32* block_groups) {
         const u32 blocks = (u32)((G + kBlock - 1) / kBlock);
         *block_groups = kBlock;
         if (CHANGED && blocks > e->counts_cap) return fail(RAFTHIP_EINVAL, "internal: counts capacity");
-        const size_t lds = (size_t)(kBlock / 64) * e->S * kTileStride * sizeof(u64);
         const int uv = uni ? (int)e->uniform_voters : 0;
+        if (e->wide_bitonic) {
+            const size_t lds = (size_t)(kBlock / 64) * e->S * kTileStride * sizeof(u64);
 #define RAFTHIP_WIDE(W, MT)                                                                        \
     hipLaunchKernelGGL((k_commit_wide<W, MT, MODE>), dim3(blocks), dim3(kBlock), lds, st,          \
                        e->match, e->stride, G, (int)e->S,                                          \
                        uni ? nullptr : static_cast<const MT*>(e->in_mask),                         \
                        uni ? nullptr : static_cast<const MT*>(e->out_mask), uv, e->commit, lb,     \
                        e->stage, e->counts)
-        if (e->S <= 16) {
-            RAFTHIP_WIDE(16, uint16_t);
-        } else if (e->S <= 32) {
-            RAFTHIP_WIDE(32, uint32_t);
-        } else {
-            RAFTHIP_WIDE(64, uint64_t);
-        }
+            if (e->S <= 16) {
+                RAFTHIP_WIDE(16, uint16_t);
+            } else if (e->S <= 32) {
+                RAFTHIP_WIDE(32, uint32_t);
+            } else {
+                RAFTHIP_WIDE(64, uint64_t);
+            }
 #undef RAFTHIP_WIDE
+        } else {
+#define RAFTHIP_REGS(N, MT)                                                                        \
+    hipLaunchKernelGGL((k_commit_regs<N, MT, MODE>), dim3(blocks), dim3(kBlock), 0, st,            \
+                       e->match, e->stride, G, (int)e->S,                                          \
+                       uni ? nullptr : static_cast<const MT*>(e->in_mask),                         \
+                       uni ? nullptr : static_cast<const MT*>(e->out_mask), uv, e->commit, lb,     \
+                       e->stage, e->counts)
+            if (e->S <= 12) {
+                RAFTHIP_REGS(12, uint16_t);
+            } else if (e->S <= 16) {
+                RAFTHIP_REGS(16, uint16_t);
+            } else if (e->S <= 24) {
+                RAFTHIP_REGS(24, uint32_t);
+            } else if (e->S <= 32) {
+                RAFTHIP_REGS(32, uint32_t);
+            } else if (e->S <= 48) {
+                RAFTHIP_REGS(48, uint64_t);
+            } else {
+                RAFTHIP_REGS(64, uint64_t);
+            }
+#undef RAFTHIP_REGS
+        }
     }
     HIP_TRY(hipGetLastError());
     e->stats.commit_launches++;
@@ -221,11 +253,12 @@ int launch_commit(rafthip_engine* e, u32* block_groups) {
 }
 
 int ensure_changed_buffers(rafthip_engine* e) {
-    const u32 bg = e->S <= 8 ? kTileGroups : kBlock;
-    const u32 blocks = (u32)((e->G + bg - 1) / bg);
+    // Sized for either tiling (a conf change may move an engine between them):
+    // tiles partition [0, stride), and kBlock is the smaller tile.
+    const u32 blocks = (u32)(e->stride / kBlock);
     int rc;
-    if ((rc = ensure(e, e->stage, (size_t)blocks * bg * sizeof(Pair), false))) return rc;
-    if ((rc = ensure(e, e->packed, (size_t)blocks * bg * sizeof(Pair), false))) return rc;
+    if ((rc = ensure(e, e->stage, (size_t)e->stride * sizeof(Pair), false))) return rc;
+    if ((rc = ensure(e, e->packed, (size_t)e->stride * sizeof(Pair), false))) return rc;
     if ((rc = ensure(e, e->counts, (size_t)blocks * sizeof(u32)))) return rc;
     if ((rc = ensure(e, e->offsets, ((size_t)blocks + 1) * sizeof(u64)))) return rc;
     e->counts_cap = blocks;
@@ -428,7 +461,7 @@ int rafthip_create(const rafthip_config* cfg, rafthip_engine** out) {
                     (u64)cfg->num_groups);
     if (cfg->num_slots == 0 || cfg->num_slots > RAFTHIP_MAX_SLOTS)
         return fail(RAFTHIP_EINVAL, "num_slots %u outside [1, %u]", cfg->num_slots, RAFTHIP_MAX_SLOTS);
-    if (cfg->flags != 0) return fail(RAFTHIP_EINVAL, "unknown flags 0x%x", cfg->flags);
+    if (cfg->flags & ~RAFTHIP_FLAG_WIDE_BITONIC) return fail(RAFTHIP_EINVAL, "unknown flags 0x%x", cfg->flags);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(RAFTHIP_ENODEV, "no HIP device available (this library has no CPU path)");
@@ -449,6 +482,7 @@ int rafthip_create(const rafthip_config* cfg, rafthip_engine** out) {
     e->S = cfg->num_slots;
     e->stride = round_up(e->G, kPlaneAlign);
     e->mbytes = mask_bytes_for(e->S);
+    e->wide_bitonic = (cfg->flags & RAFTHIP_FLAG_WIDE_BITONIC) != 0;
     int rc = RAFTHIP_OK;
     do {
         if (cfg->stream) {

@@ -1,5 +1,6 @@
-// sortnet.h — minimal-size sorting networks for 1..8 keys, used in registers by
-// the lane-per-group commit kernels.  The reference sorts the <=7 voter indexes
+// sortnet.h — sorting networks used in registers by the lane-per-group commit
+// kernels: minimal-size networks for 1..8 keys (SortNet), and Batcher's
+// odd-even merge sort pruned to N keys for 9..64 (Batcher).  The reference sorts the <=7 voter indexes
 // with an insertion sort on the stack (quorum/majority.go:115-122,141-147); a
 // fixed compare-exchange network gives the same sorted order with no
 // data-dependent branches, which is what a 64-wide wavefront wants.
@@ -77,6 +78,58 @@ constexpr bool sortnet_sorts_all_01() {
     }
     return true;
 }
+
+// ---------------------------------------------------------------------------
+// Batcher's odd-even merge sort for P = 2^k keys (Knuth 5.2.2, merge exchange),
+// pruned to the comparators that touch only keys < N: imagine keys N..P-1 as
+// +infinity — a compare-exchange never moves them, so dropping those
+// comparators sorts the first N keys all the same.  63 / 191 / 543
+// comparators at N = 16 / 32 / 64.  Generated at compile time; the 0-1 check
+// below covers N <= 12 (2^N inputs), tests/sortnet_check.cpp the rest.
+// ---------------------------------------------------------------------------
+template <int N>
+struct Batcher {
+    static constexpr int P = N <= 2 ? 2 : N <= 4 ? 4 : N <= 8 ? 8 : N <= 16 ? 16 : N <= 32 ? 32 : 64;
+    static_assert(N >= 2 && N <= 64, "Batcher network: 2..64 keys");
+    struct List {
+        CE ce[543];
+        int n;
+    };
+    static constexpr List make() {
+        List l{};
+        l.n = 0;
+        for (int p = 1; p < P; p <<= 1)
+            for (int k = p; k >= 1; k >>= 1)
+                for (int j = k % p; j + k < P; j += 2 * k)
+                    for (int i = 0; i < k && i + j + k < P; ++i)
+                        if ((i + j) / (2 * p) == (i + j + k) / (2 * p)) {
+                            const int a = i + j, b = i + j + k;
+                            if (b < N) l.ce[l.n++] = CE{(uint8_t)a, (uint8_t)b};
+                        }
+        return l;
+    }
+    static constexpr List list = make();
+    static constexpr int n = list.n;
+};
+
+template <int N>
+constexpr bool batcher_sorts_all_01() {
+    for (unsigned in = 0; in < (1u << N); ++in) {
+        unsigned v = in;
+        for (int k = 0; k < Batcher<N>::n; ++k) {
+            const unsigned a = Batcher<N>::list.ce[k].a, b = Batcher<N>::list.ce[k].b;
+            const unsigned va = (v >> a) & 1u, vb = (v >> b) & 1u;
+            if (va > vb) v ^= (1u << a) | (1u << b);
+        }
+        for (int i = 0; i + 1 < N; ++i)
+            if (((v >> i) & 1u) > ((v >> (i + 1)) & 1u)) return false;
+    }
+    return true;
+}
+static_assert(Batcher<16>::n == 63 && Batcher<32>::n == 191 && Batcher<64>::n == 543, "Batcher comparator counts");
+static_assert(batcher_sorts_all_01<5>() && batcher_sorts_all_01<8>() && batcher_sorts_all_01<9>() &&
+                  batcher_sorts_all_01<12>(),
+              "pruned Batcher networks");
 
 static_assert(sortnet_sorts_all_01<1>(), "sorting network 1");
 static_assert(sortnet_sorts_all_01<2>(), "sorting network 2");

@@ -35,7 +35,8 @@ def test_commit_advance_testcommit_table():
                 assert pairs["group"][0] == 0 and pairs["commit"][0] == row["w"]
 
 
-@pytest.mark.parametrize("S,mode", [(5, "uniform"), (3, "uniform"), (6, "masked"), (8, "masked"), (12, "wide"), (40, "wide")])
+@pytest.mark.parametrize("S,mode", [(5, "uniform"), (3, "uniform"), (6, "masked"), (8, "masked"), (12, "wide"), (40, "wide"),
+                                    (12, "bitonic"), (40, "bitonic")])
 def test_commit_advance_random_logs(oracle, S, mode):
     rng = np.random.default_rng(700 + S)
     G = 30011 if S <= 8 else 3001
@@ -54,7 +55,7 @@ def test_commit_advance_random_logs(oracle, S, mode):
     match = np.minimum(match, (last[None, :] + 2).astype(np.uint64))
     match = np.ascontiguousarray(match)
     tf, tl = gu.term_range(off, terms, first, snap, term)
-    with raft_amd.Engine(G, S) as e:
+    with raft_amd.Engine(G, S, flags=raft_amd.capi.FLAG_WIDE_BITONIC if mode == "bitonic" else 0) as e:
         if mode == "uniform":
             e.set_uniform_config(S)
             kw = dict(uniform_voters=S)

@@ -148,13 +148,16 @@ def test_commit_masked_small(oracle, S):
     assert np.array_equal(got, oracle.batch_committed(match, m0, m1))
 
 
-@pytest.mark.parametrize("S", [9, 11, 16, 17, 25, 32, 33, 48, 63, 64])
-def test_commit_wide(oracle, S):
+@pytest.mark.parametrize("flags", [0, raft_amd.capi.FLAG_WIDE_BITONIC], ids=["regs", "bitonic"])
+@pytest.mark.parametrize("S", [9, 11, 12, 13, 16, 17, 24, 25, 32, 33, 48, 49, 63, 64])
+def test_commit_wide(oracle, S, flags):
+    """Both wide kernels: the register Batcher network (default) and the
+    cross-lane wave64 bitonic network (RAFTHIP_FLAG_WIDE_BITONIC)."""
     rng = np.random.default_rng(300 + S)
     G = 3001
     match = rand_match(rng, S, G)
     m0, m1 = rand_masks(rng, S, G)
-    with raft_amd.Engine(G, S) as e:
+    with raft_amd.Engine(G, S, flags=flags) as e:
         e.upload_config(m0, m1)
         e.upload_match(match)
         e.commit()
@@ -167,14 +170,15 @@ def test_commit_wide(oracle, S):
         assert np.array_equal(e.read_commit(), oracle.batch_committed(match, uniform_voters=V))
 
 
-def test_commit_wide_non_joint_wave(oracle):
+@pytest.mark.parametrize("flags", [0, raft_amd.capi.FLAG_WIDE_BITONIC], ids=["regs", "bitonic"])
+def test_commit_wide_non_joint_wave(oracle, flags):
     """All-non-joint wavefronts take the skip-outgoing branch."""
     rng = np.random.default_rng(5)
     S, G = 20, 1000
     match = rand_match(rng, S, G)
     m0, _ = rand_masks(rng, S, G)
     m1 = np.zeros_like(m0)
-    with raft_amd.Engine(G, S) as e:
+    with raft_amd.Engine(G, S, flags=flags) as e:
         e.upload_config(m0, m1)
         e.upload_match(match)
         e.commit()
@@ -268,13 +272,14 @@ def test_scatter_then_commit(oracle, S, G):
         assert st["acks_applied"] == N
 
 
-@pytest.mark.parametrize("S,uniform", [(5, True), (6, False), (12, False)])
-def test_commit_changed_pairs(oracle, S, uniform):
+@pytest.mark.parametrize("S,uniform,flags", [(5, True, 0), (6, False, 0), (12, False, 0), (12, False, 1), (40, False, 0),
+                                              (12, True, 0)])
+def test_commit_changed_pairs(oracle, S, uniform, flags):
     rng = np.random.default_rng(600 + S)
     G = 30011
     match = rng.integers(1, 1 << 30, size=(S, G), dtype=np.uint64)
     m0, m1 = rand_masks(rng, S, G, empty_frac=0)
-    with raft_amd.Engine(G, S) as e:
+    with raft_amd.Engine(G, S, flags=flags) as e:
         if uniform:
             e.set_uniform_config(S)
             kw = dict(uniform_voters=S)
@@ -282,6 +287,13 @@ def test_commit_changed_pairs(oracle, S, uniform):
             e.upload_config(m0, m1)
             kw = dict(in_mask=m0, out_mask=m1)
         e.upload_match(match)
+        if S == 12 and not uniform and not flags:
+            # an engine may move between the two tilings: uniform <= 8 voters runs K1 even at S = 12
+            e.set_uniform_config(7)
+            _, n7 = e.commit_changed(max_pairs=0)
+            assert n7 == G and np.array_equal(e.read_commit(), oracle.batch_committed(match, uniform_voters=7))
+            e.upload_commit(np.zeros(G, dtype=np.uint64))
+            e.upload_config(m0, m1)
         want0 = oracle.batch_committed(match, **kw)
         pairs, n = e.commit_changed()
         nz = np.flatnonzero(want0 != 0)

@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""Per-kernel roofline numbers for every kernel of the engine at the sizes
+BASELINE.json's configs name — a development tool;
+bench.py stays the headline line.
+
+Each row: kernel, units per launch, algorithmic bytes per unit,
+average launch duration from HIP events on the engine's stream over `--iters`
+back-to-back launches, achieved GB/s and the fraction of the 8 TB/s HBM peak.
+Working sets are chosen larger than the 256 MiB Infinity Cache so the passes
+read HBM.  Run under `rocprofv3 --kernel-trace --stats` for the matching
+per-kernel averages.
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK = 8000.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--scale", type=int, default=0, help="log2 shrink of every G (for quick runs)")
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+
+    import torch
+
+    import golden_util as gu
+    import raft_amd
+
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    stream = torch.cuda.Stream(device=dev)
+    rows = []
+
+    def timed(name, unit, units, bytes_per_unit, fn, setup=None, iters=None):
+        if args.only and args.only not in name:
+            return
+        iters = iters or args.iters
+        with torch.cuda.stream(stream):
+            for _ in range(3):
+                if setup:
+                    setup()
+                fn()
+            torch.cuda.synchronize()
+            tot = 0.0
+            if setup is None:  # back-to-back launches between two events: no host gap inside
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                for _ in range(iters):
+                    fn()
+                e1.record(stream)
+                e1.synchronize()
+                tot = e0.elapsed_time(e1)
+            else:
+                for _ in range(iters):
+                    setup()
+                    torch.cuda.synchronize()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(stream)
+                    fn()
+                    e1.record(stream)
+                    e1.synchronize()
+                    tot += e0.elapsed_time(e1)
+        us = 1e3 * tot / iters
+        gbs = units * bytes_per_unit / us / 1e3
+        row = {"kernel": name, "unit": unit, "units_per_launch": units, "bytes_per_unit": bytes_per_unit,
+               "avg_launch_us": round(us, 2), "achieved_GBs": round(gbs, 1), "frac_of_8TBs": round(gbs / HBM_PEAK, 3),
+               "units_per_s": units / us * 1e6}
+        rows.append(row)
+        print(json.dumps(row), flush=True)
+
+    sh = args.scale
+    S = raft_amd.capi
+
+    # ---- cfg2: 2^20 x 3 voters is cache-sized; measure the same kernel at 2^24 -------------
+    G = (1 << 24) >> sh
+    for V in (3, 5, 7):
+        m = gu.dist_a(0x5EED0002, V, G)
+        with raft_amd.Engine(G, V, stream=stream.cuda_stream) as e:
+            e.set_uniform_config(V)
+            e.upload_match(m)
+            timed("k_commit_uniform<%d> (K1)" % V, "group", G, 8 * V + 8, e.commit)
+            if V == 5:
+                tf = np.zeros(G, dtype=np.uint64)
+                tl = np.full(G, gu.U64MAX, dtype=np.uint64)
+                e.upload_term_range(tf, tl)
+                zero = np.zeros(G, dtype=np.uint64)
+                # commit_changed / commit_advance include the scan + pack kernels and a sync;
+                # the commit plane is reset before each launch so every group reports
+                timed("commit_changed, all groups change (K1+scan+pack)", "group", G, 8 * V + 16 + 32,
+                      lambda: e.commit_changed(max_pairs=0), setup=lambda: e.upload_commit(zero), iters=5)
+                timed("commit_changed, nothing changes (K1+scan+pack)", "group", G, 8 * V + 16,
+                      lambda: e.commit_changed(max_pairs=0), iters=5)
+                timed("commit_advance, nothing advances (K1 kAdvance+scan+pack)", "group", G, 8 * V + 32,
+                      lambda: e.commit_advance(max_pairs=0), iters=5)
+                timed("k_heartbeat_commit (K6)", "group", G, 16 * V + 8,
+                      lambda: e.heartbeat_commit(download=False))
+        del m
+
+    # ---- cfg3: joint configs, S = 6 ---------------------------------------------------------
+    from test_gpu_fullsize import cfg3_masks
+    G = (1 << 24) >> sh
+    m = gu.dist_a(0x5EED0003, 6, G)
+    m0, m1 = cfg3_masks(G, 0x5EED0003)
+    with raft_amd.Engine(G, 6, stream=stream.cuda_stream) as e:
+        e.upload_config(m0, m1)
+        e.upload_match(m)
+        timed("k_commit_masked<6> cfg3 mix (K2)", "group", G, 8 * 6 + 2 + 8, e.commit)
+        e.upload_config(m0, np.zeros_like(m0))
+        timed("k_commit_masked<6> no joint group (K2)", "group", G, 8 * 6 + 2 + 8, e.commit)
+    del m
+
+    # ---- wide voters ------------------------------------------------------------------------
+    for Sw in (9, 16, 32, 64):
+        G = (1 << 22) >> sh
+        rng = np.random.default_rng(Sw)
+        m = rng.integers(0, 1 << 62, size=(Sw, G), dtype=np.uint64)
+        mdt = gu.mask_dtype(Sw)
+        full = mdt((1 << Sw) - 1 if Sw < 64 else gu.U64MAX)
+        for flags, kname in ((0, "k_commit_regs (K4r)"), (raft_amd.capi.FLAG_WIDE_BITONIC, "k_commit_wide bitonic (K4)")):
+            with raft_amd.Engine(G, Sw, stream=stream.cuda_stream, flags=flags) as e:
+                e.upload_config(np.full(G, full, dtype=mdt), np.zeros(G, dtype=mdt))
+                e.upload_match(m)
+                timed("%s S=%d non-joint" % (kname, Sw), "group", G, 8 * Sw + 2 * mdt().itemsize + 8, e.commit)
+                e.upload_config(np.full(G, full, dtype=mdt), np.full(G, full >> mdt(1), dtype=mdt))
+                timed("%s S=%d joint" % (kname, Sw), "group", G, 8 * Sw + 2 * mdt().itemsize + 8, e.commit)
+        del m
+
+    # ---- cfg4: tallies ----------------------------------------------------------------------
+    G = (1 << 26) >> sh
+    rng = np.random.default_rng(4)
+    lut = np.array([2, 2, 1, 0, 0], dtype=np.uint8)
+    votes = lut[rng.integers(0, 5, size=(5, G), dtype=np.uint8)]
+    bits = rng.integers(0, 32, size=G, dtype=np.uint8)
+    with raft_amd.Engine(G, 5, stream=stream.cuda_stream) as e:
+        e.set_uniform_config(5)
+        e.upload_votes(votes)
+        e.upload_active(bits)
+        e.upload_acks(bits)
+        e.upload_self(np.ones(G, dtype=np.uint8))
+        timed("k_tally_votes_small<5> uniform (K3)", "group", G, 5 + 3, e.tally_votes)
+        timed("k_tally_bits_small QuorumActive (K3)", "group", G, 2, e.quorum_active)
+        timed("k_tally_bits_small ack quorum (K3)", "group", G, 2, e.ack_quorum)
+        timed("k_tally_bits_small CheckQuorum + reset (K3)", "group", G, 4, e.check_quorum)
+        m0 = np.full(G, 0b11111, dtype=np.uint8)
+        e.upload_config(m0, m0 >> 1, np.zeros(G, dtype=np.uint8))
+        timed("k_tally_votes_small<5> masked joint (K3)", "group", G, 5 + 3 + 3, e.tally_votes)
+    del votes, bits
+
+    # ---- cfg5: ack scatter / message ingest, 7 voters + 2 learners ---------------------------
+    G = (1 << 22) >> sh
+    Sv = 9
+    m = gu.dist_a(0x5EED0005, Sv, G)
+    N = 4 * G
+    rng = np.random.default_rng(5)
+    recs = np.zeros(N, dtype=raft_amd.ACK_DTYPE)
+    recs["group"] = rng.integers(0, G, size=N, dtype=np.uint32)
+    recs["slot"] = rng.integers(0, Sv, size=N, dtype=np.uint32)
+    recs["index"] = rng.integers(0, 1 << 62, size=N, dtype=np.uint64)
+    msgs = np.zeros(N, dtype=raft_amd.MSG_DTYPE)
+    msgs["group"], msgs["slot"], msgs["index"] = recs["group"], recs["slot"], recs["index"]
+    msgs["type"] = rng.choice(np.array([4, 9], dtype=np.uint8), size=N, p=[0.7, 0.3])
+    msgs["flags"] = 1
+    d_recs = torch.from_numpy(recs.view(np.uint8)).to(dev)
+    d_msgs = torch.from_numpy(msgs.view(np.uint8)).to(dev)
+    with raft_amd.Engine(G, Sv, stream=stream.cuda_stream) as e:
+        e.set_uniform_config(7)
+        e.upload_match(m)
+        timed("k_scatter_acks, random cells (K5)", "ack", N, 24, lambda: e.scatter_acks(d_recs.data_ptr(), N))
+        timed("k_ingest_msgs, random cells (K7)", "msg", N, 24 + 4, lambda: e.ingest_msgs(d_msgs.data_ptr(), N))
+        timed("k_commit_uniform<7> over 9 slots (K1)", "group", G, 64, e.commit)
+    # sorted-by-group stream (a host that buckets acks by range)
+    order = np.argsort(recs["group"], kind="stable")
+    d_recs = torch.from_numpy(np.ascontiguousarray(recs[order]).view(np.uint8)).to(dev)
+    with raft_amd.Engine(G, Sv, stream=stream.cuda_stream) as e:
+        e.set_uniform_config(7)
+        e.upload_match(m)
+        timed("k_scatter_acks, group-sorted stream (K5)", "ack", N, 24, lambda: e.scatter_acks(d_recs.data_ptr(), N))
+
+    print("\n| kernel | units/launch | B/unit | avg µs | GB/s | of 8 TB/s | units/s |")
+    print("|---|---|---|---|---|---|---|")
+    for r in rows:
+        print("| %s | %d | %d | %.1f | %.0f | %.1f %% | %.3g |" % (
+            r["kernel"], r["units_per_launch"], r["bytes_per_unit"], r["avg_launch_us"], r["achieved_GBs"],
+            100 * r["frac_of_8TBs"], r["units_per_s"]))
+
+
+if __name__ == "__main__":
+    main()
