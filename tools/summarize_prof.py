@@ -3,6 +3,9 @@
 
   summarize_prof.py stats  <dir> <out.csv>          --kernel-trace --stats run: per-kernel calls / avg / total
   summarize_prof.py pmc    <out.csv> <dir> [<dir>…]  --pmc runs: per (counter, kernel) dispatches and avg/min/max KB
+  summarize_prof.py traffic <pmc_summary.csv> <kernel substring> <groups> <bytes/group> <out.json>
+                                                     HBM bytes per launch of one kernel, with the gfx950
+                                                     FETCH_SIZE x2 correction (MI355X_MICROARCH.md, HBM section)
 """
 import csv
 import glob
@@ -41,8 +44,34 @@ def pmc(out, dirs):
             w.writerow([c, k, g, len(v), sum(v) / len(v), min(v), max(v)])
 
 
+def traffic(summary, kernel, groups, bytes_per_group, out):
+    import json
+    fetch = write = None
+    for r in csv.DictReader(open(summary)):
+        if kernel in r["Kernel"]:
+            if r["Counter"] == "FETCH_SIZE":
+                fetch = float(r["AvgKB"])
+            elif r["Counter"] == "WRITE_SIZE":
+                write = float(r["AvgKB"])
+    if fetch is None or write is None:
+        raise SystemExit("kernel %r not found with both counters in %s" % (kernel, summary))
+    doc = {
+        "kernel": kernel, "groups_per_launch": groups, "fetch_size_kb_avg": fetch, "write_size_kb_avg": write,
+        "fetch_bytes_corrected": fetch * 1024 * 2, "write_bytes": write * 1024,
+        "hbm_bytes_per_launch": fetch * 1024 * 2 + write * 1024,
+        "algorithmic_bytes_per_launch": groups * bytes_per_group,
+        "note": "FETCH_SIZE (KB) x1024 x2: on gfx950 FETCH_SIZE reports half the bytes of a wide coalesced "
+                "streaming read (MI355X_MICROARCH.md, HBM section); WRITE_SIZE (KB) x1024 is exact for "
+                "16-B/lane stores.  Separate --pmc passes.",
+        "source": summary,
+    }
+    json.dump(doc, open(out, "w"), indent=1)
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3])
+    elif sys.argv[1] == "traffic":
+        traffic(sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), sys.argv[6])
     else:
         pmc(sys.argv[2], sys.argv[3:])
