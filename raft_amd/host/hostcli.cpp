@@ -15,6 +15,9 @@
 //   reset <g> | ack <g> <id> <n> | commit | commitof <g> | matchof <g> <id>
 //   recordvote <g> <id> y|n | resetvotes <g> | tally | voteof <g>
 //   active <g> <id> 0|1 | quorumactive | recvack <g> <id> | resetacks <g> | ackquorum
+//   leader <g> <self> <term_first> <last_index> | follower <g> | setcommitted <g> <c>
+//   appended <g> <last_index> | step <g> <from> <type> <index> <reject 0|1> <ctx 0|1>
+//   maybecommit | checkquorum | hbcommit <g> <id>
 // Any failure prints "error <code> <text>" and processing continues.
 #include <inttypes.h>
 #include <stdio.h>
@@ -189,6 +192,33 @@ int main() {
                     for (auto x : a) putchar('0' + (int)x);
                     printf("\n");
                 }
+            } else if (cmd == "leader") {
+                rc = trk->SetLeader(u(1), u(2), u(3), u(4));
+            } else if (cmd == "follower") {
+                rc = trk->SetFollower(u(1));
+            } else if (cmd == "setcommitted") {
+                rc = trk->SetCommitted(u(1), u(2));
+            } else if (cmd == "appended") {
+                if (!trk->Appended(u(1), u(2))) printf("dropped\n");
+            } else if (cmd == "step") {
+                if (!trk->Step(u(1), u(2), (int)u(3), u(4), u(5) != 0, u(6) != 0)) printf("dropped\n");
+            } else if (cmd == "maybecommit") {
+                std::vector<tracker::CommitPair> adv;
+                if (!(rc = trk->MaybeCommit(&adv))) {
+                    for (const auto& p : adv) printf("advanced %" PRIu64 " %" PRIu64 "\n", p.group, p.commit);
+                    printf("maybecommit-done %zu\n", adv.size());
+                }
+            } else if (cmd == "checkquorum") {
+                std::vector<uint8_t> a;
+                if (!(rc = trk->CheckQuorum(&a))) {
+                    printf("checkquorum ");
+                    for (uint8_t x : a) putchar('0' + x);
+                    printf("\n");
+                }
+            } else if (cmd == "hbcommit") {
+                uint64_t c = 0;
+                if (!(rc = trk->HeartbeatCommit(u(1), u(2), &c)))
+                    printf("hbcommit %" PRIu64 " %" PRIu64 " %" PRIu64 "\n", u(1), u(2), c);
             } else {
                 rc = RAFTHIP_EINVAL;
                 err = "unknown command";

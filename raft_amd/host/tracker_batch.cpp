@@ -53,6 +53,7 @@ int BatchProgressTracker::Make(int device, uint64_t groups, uint32_t max_slots, 
     t->votes_.assign((size_t)max_slots * groups, RAFTHIP_CELL_NONE);
     t->active_.assign(groups * t->mb_, 0);
     t->rdacks_.assign(groups * t->mb_, 0);
+    t->self_.assign(groups * t->mb_, 0);
     t->pairs_.resize(groups);
     // the engine must see zeroed bit planes even if no bit is ever set
     t->touch(t->active_dirty_, 0);
@@ -142,6 +143,10 @@ int BatchProgressTracker::SetConfig(uint64_t group, const quorum::MajorityConfig
             touch(votes_dirty_, group);
         }
         if ((rdacks >> s) & 1ull) stray_acks_[group].insert(ids[s]);  // acks are keyed by id too (read_only.go:29-37)
+        if ((get_mask(self_, group) >> s) & 1ull) {  // the leader itself left the config
+            put_mask(self_, group, 0);
+            touch(self_dirty_, group);
+        }
         used &= ~(1ull << s);
         active &= ~(1ull << s);
         rdacks &= ~(1ull << s);
@@ -212,9 +217,16 @@ bool BatchProgressTracker::MaybeUpdate(uint64_t group, uint64_t id, uint64_t n) 
 }
 
 int BatchProgressTracker::Flush() {
-    if (acks_.empty()) return RAFTHIP_OK;
-    int rc = lib(rafthip_scatter_acks(e_, acks_.data(), acks_.size()));
-    acks_.clear();
+    int rc = RAFTHIP_OK;
+    if (!acks_.empty()) {
+        rc = lib(rafthip_scatter_acks(e_, acks_.data(), acks_.size()));
+        acks_.clear();
+        if (rc) return rc;
+    }
+    if (!msgs_.empty()) {
+        rc = lib(rafthip_ingest_msgs(e_, msgs_.data(), msgs_.size()));
+        msgs_.clear();
+    }
     return rc;
 }
 
@@ -312,6 +324,12 @@ int BatchProgressTracker::SetRecentActive(uint64_t group, uint64_t id, bool acti
 
 int BatchProgressTracker::QuorumActive(std::vector<uint8_t>* active) {
     if (!active) return fail(RAFTHIP_EINVAL, "active is NULL");
+    {
+        // queued responses carry the same bit updates the shadow already has;
+        // apply them before the shadow overwrites the device plane
+        int frc = Flush();
+        if (frc) return frc;
+    }
     if (active_dirty_[0] <= active_dirty_[1]) {
         const uint64_t first = active_dirty_[0], count = active_dirty_[1] - active_dirty_[0] + 1;
         int rc = lib(rafthip_upload_active(e_, first, count, active_.data() + first * mb_));
@@ -351,6 +369,10 @@ int BatchProgressTracker::ResetAcks(uint64_t group) {
 
 int BatchProgressTracker::AckQuorum(std::vector<quorum::VoteResult>* result) {
     if (!result) return fail(RAFTHIP_EINVAL, "result is NULL");
+    {
+        int frc = Flush();
+        if (frc) return frc;
+    }
     if (rdacks_dirty_[0] <= rdacks_dirty_[1]) {
         const uint64_t first = rdacks_dirty_[0], count = rdacks_dirty_[1] - rdacks_dirty_[0] + 1;
         int rc = lib(rafthip_upload_acks(e_, first, count, rdacks_.data() + first * mb_));
@@ -363,6 +385,128 @@ int BatchProgressTracker::AckQuorum(std::vector<quorum::VoteResult>* result) {
     result->assign(G_, quorum::VotePending);
     static_assert(sizeof(quorum::VoteResult) == 1, "VoteResult is uint8 (quorum/quorum.go:48)");
     return lib(rafthip_read_ack_quorum(e_, 0, G_, reinterpret_cast<uint8_t*>(result->data())));
+}
+
+// ---- the leader-side tick ----------------------------------------------------
+
+int BatchProgressTracker::SetLeader(uint64_t group, uint64_t self, uint64_t term_first, uint64_t last_index) {
+    if (group >= G_) return fail(RAFTHIP_ERANGE, "group %llu outside [0, %llu)", (unsigned long long)group,
+                                 (unsigned long long)G_);
+    int rc = Flush();
+    if (rc) return rc;
+    if ((rc = lib(rafthip_upload_term_range(e_, group, 1, &term_first, &last_index)))) return rc;
+    const int s = slot_of(group, self);  // a leader removed from the config has no Progress row
+    put_mask(self_, group, s < 0 ? 0 : (1ull << s));
+    touch(self_dirty_, group);
+    if (s >= 0) {
+        put_mask(active_, group, get_mask(active_, group) | (1ull << s));
+        touch(active_dirty_, group);
+    }
+    return RAFTHIP_OK;
+}
+
+int BatchProgressTracker::SetFollower(uint64_t group) {
+    if (group >= G_) return fail(RAFTHIP_ERANGE, "group %llu outside [0, %llu)", (unsigned long long)group,
+                                 (unsigned long long)G_);
+    int rc = Flush();
+    if (rc) return rc;
+    const uint64_t first = 1, last = 0;  // empty range
+    if ((rc = lib(rafthip_upload_term_range(e_, group, 1, &first, &last)))) return rc;
+    put_mask(self_, group, 0);
+    touch(self_dirty_, group);
+    return RAFTHIP_OK;
+}
+
+int BatchProgressTracker::SetCommitted(uint64_t group, uint64_t committed) {
+    int rc = Flush();
+    if (rc) return rc;
+    return lib(rafthip_upload_commit(e_, group, 1, &committed));
+}
+
+bool BatchProgressTracker::Appended(uint64_t group, uint64_t last_index) {
+    if (group >= G_) return false;
+    rafthip_msg m;
+    memset(&m, 0, sizeof(m));
+    m.group = (uint32_t)group;
+    m.type = RAFTHIP_MSG_APPENDED;
+    m.index = last_index;
+    msgs_.push_back(m);
+    return true;
+}
+
+bool BatchProgressTracker::Step(uint64_t group, uint64_t from, int type, uint64_t index, bool reject,
+                                bool read_ctx) {
+    if (group >= G_) return false;
+    if (type != RAFTHIP_MSG_APP_RESP && type != RAFTHIP_MSG_HEARTBEAT_RESP) return false;
+    const int s = slot_of(group, from);
+    if (s < 0) return false;
+    // The bit planes are host-shadowed (uploaded lazily before a tally), so the
+    // shadow takes the same update the kernel applies on the device.
+    put_mask(active_, group, get_mask(active_, group) | (1ull << s));
+    touch(active_dirty_, group);
+    if (type == RAFTHIP_MSG_HEARTBEAT_RESP && read_ctx) {
+        put_mask(rdacks_, group, get_mask(rdacks_, group) | (1ull << s));
+        touch(rdacks_dirty_, group);
+    }
+    rafthip_msg m;
+    memset(&m, 0, sizeof(m));
+    m.group = (uint32_t)group;
+    m.slot = (uint8_t)s;
+    m.type = (uint8_t)type;
+    m.reject = reject ? 1 : 0;
+    m.flags = read_ctx ? RAFTHIP_MSGF_READ_CTX : 0;
+    m.index = index;
+    msgs_.push_back(m);
+    return true;
+}
+
+int BatchProgressTracker::MaybeCommit(std::vector<CommitPair>* advanced) {
+    int rc = Flush();
+    if (rc) return rc;
+    uint64_t n = 0;
+    rc = lib(rafthip_commit_advance(e_, reinterpret_cast<rafthip_commit_pair*>(pairs_.data()), pairs_.size(), &n));
+    if (rc) return rc;
+    if (advanced) advanced->assign(pairs_.begin(), pairs_.begin() + (n < pairs_.size() ? n : pairs_.size()));
+    return RAFTHIP_OK;
+}
+
+int BatchProgressTracker::CheckQuorum(std::vector<uint8_t>* active) {
+    if (!active) return fail(RAFTHIP_EINVAL, "active is NULL");
+    int rc = Flush();  // queued responses set RecentActive on the device too; same bits as the shadow
+    if (rc) return rc;
+    if (active_dirty_[0] <= active_dirty_[1]) {
+        const uint64_t first = active_dirty_[0], count = active_dirty_[1] - active_dirty_[0] + 1;
+        if ((rc = lib(rafthip_upload_active(e_, first, count, active_.data() + first * mb_)))) return rc;
+        active_dirty_[0] = 1;
+        active_dirty_[1] = 0;
+    }
+    if (self_dirty_[0] <= self_dirty_[1]) {
+        const uint64_t first = self_dirty_[0], count = self_dirty_[1] - self_dirty_[0] + 1;
+        if ((rc = lib(rafthip_upload_self(e_, first, count, self_.data() + first * mb_)))) return rc;
+        self_dirty_[0] = 1;
+        self_dirty_[1] = 0;
+    }
+    if ((rc = lib(rafthip_check_quorum(e_)))) return rc;
+    active->assign(G_, 0);
+    if ((rc = lib(rafthip_read_quorum_active(e_, 0, G_, active->data())))) return rc;
+    // the engine cleared every RecentActive but self; the shadow follows
+    for (size_t i = 0; i < active_.size(); ++i) active_[i] &= self_[i];
+    return RAFTHIP_OK;
+}
+
+int BatchProgressTracker::HeartbeatCommit(uint64_t group, uint64_t id, uint64_t* commit) {
+    if (!commit) return fail(RAFTHIP_EINVAL, "commit is NULL");
+    if (group >= G_) return fail(RAFTHIP_ERANGE, "group %llu outside [0, %llu)", (unsigned long long)group,
+                                 (unsigned long long)G_);
+    const int s = slot_of(group, id);
+    if (s < 0) return fail(RAFTHIP_EINVAL, "group %llu has no Progress for id %llu", (unsigned long long)group,
+                           (unsigned long long)id);
+    int rc = Flush();
+    if (rc) return rc;
+    std::vector<uint64_t> row(S_, 0);
+    if ((rc = lib(rafthip_heartbeat_commit(e_, group, 1, row.data(), 1)))) return rc;
+    *commit = row[s];
+    return RAFTHIP_OK;
 }
 
 }  // namespace tracker

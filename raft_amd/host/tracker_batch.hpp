@@ -86,6 +86,34 @@ class BatchProgressTracker {
     int ResetAcks(uint64_t group);
     int AckQuorum(std::vector<quorum::VoteResult>* result);
 
+    // ---- the leader-side tick with the steps either side of the quorum maths ----
+    // (use either Committed() or MaybeCommit() on one tracker: the first keeps the
+    //  last quorum index in the engine's commit plane, the second raftLog.committed)
+
+    // becomeLeader (raft.go:905-936): `self` is r.id; the entries carrying r.Term
+    // are the log indexes [term_first, last_index] (the empty entry appended at
+    // becomeLeader is the first one).  Also marks self RecentActive (raft.go:920).
+    int SetLeader(uint64_t group, uint64_t self, uint64_t term_first, uint64_t last_index);
+    // Any other role: raftLog.maybeCommit can never pass (term(i) != r.Term).
+    int SetFollower(uint64_t group);
+    // raftLog.committed as the host knows it (restore, follower-side commits).
+    int SetCommitted(uint64_t group, uint64_t committed);
+    // appendEntry on the leader (raft.go:787-819): lastIndex grew.
+    bool Appended(uint64_t group, uint64_t last_index);
+    // stepLeader's bookkeeping for one response (raft.go:1327-1561): type is
+    // RAFTHIP_MSG_APP_RESP or RAFTHIP_MSG_HEARTBEAT_RESP; read_ctx says the
+    // heartbeat response names the group's pending ReadIndex request.  Returns
+    // false when there is no Progress for `from` (raft.go:1327-1331).
+    bool Step(uint64_t group, uint64_t from, int type, uint64_t index, bool reject, bool read_ctx);
+    // raft.maybeCommit for every group (raft.go:755-758): *advanced receives the
+    // groups whose raftLog.committed moved, sorted by group.
+    int MaybeCommit(std::vector<CommitPair>* advanced);
+    // The MsgCheckQuorum step for every group (raft.go:1231-1243): verdicts as
+    // QuorumActive(), then RecentActive = false for all but each group's self.
+    int CheckQuorum(std::vector<uint8_t>* active);
+    // sendHeartbeat's commit for peer `id` (raft.go:669-685), after MaybeCommit().
+    int HeartbeatCommit(uint64_t group, uint64_t id, uint64_t* commit);
+
     rafthip_engine* engine() { return e_; }
 
    private:
@@ -107,6 +135,9 @@ class BatchProgressTracker {
     std::vector<uint64_t> used_;     // [G] slots that hold a Progress
     std::vector<uint8_t> in_, out_, learner_;  // [G] masks, mb_ bytes each
     std::vector<rafthip_ack> acks_;  // queued MaybeUpdate calls
+    std::vector<rafthip_msg> msgs_;  // queued Step / Appended calls
+    std::vector<uint8_t> self_;      // [G] masks: the leader's own slot
+    uint64_t self_dirty_[2] = {1, 0};
     std::vector<CommitPair> pairs_;  // landing buffer of Committed(), G entries
     // Votes is keyed by id, not by Progress (tracker/tracker.go:122,260-265):
     // votes of ids that hold no slot right now wait here until ResetVotes.

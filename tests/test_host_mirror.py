@@ -189,7 +189,12 @@ def rand_config(rng, S, pool):
         free = [i for i in pool if i not in inc | out]
         lrn = set(rng.choice(free, size=min(room, int(rng.integers(1, 3)), len(free)), replace=False).tolist())
     while len(inc | out | lrn) > S:
-        (lrn or inc).pop()
+        if lrn:
+            lrn.pop()
+        elif inc - out:
+            inc.discard(sorted(inc - out)[0])
+        else:
+            inc.discard(out.pop())
     if not inc:
         inc = {int(pool[0])}
     return inc, out, lrn - inc - out
@@ -281,3 +286,96 @@ def test_tracker_scenarios(oracle, S, G, seed):
     for k, (a, b) in enumerate(zip(out, want)):
         assert a == b, (k, a, b)
     assert len(out) == len(want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("S,G,seed", [(7, 48, 4), (12, 20, 5)])
+def test_tracker_leader_tick(oracle, S, G, seed):
+    """The leader-side tick through the host mirror: responses stepped in
+    (raft.go:1327-1561), raft.maybeCommit with the term guard (raft.go:755-758,
+    log.go:447-456), heartbeat commits (raft.go:669-685), MsgCheckQuorum
+    (raft.go:1231-1243) — against the id-keyed model."""
+    rng = np.random.default_rng(seed)
+    pool = np.arange(1, S + 4)
+    m = Model(G)
+    committed = [0] * G
+    rng_state = [None] * G  # (self, term_first, last_index) for leaders
+    script, want = ["tracker %d %d" % (G, S)], ["tracker ok"]
+    for g in range(G):
+        inc, out, lrn = rand_config(rng, S, pool)
+        m.set_config(g, inc, out, lrn)
+        script.append("setconfig %d in=%s out=%s learners=%s" % (g, ids(inc), ids(out), ids(lrn)))
+        for i in m.active[g]:
+            m.active[g][i] = False
+            script.append("active %d %d 0" % (g, i))
+        if rng.random() < 0.85:
+            self_id = int(rng.choice(sorted(inc | out))) if rng.random() < 0.9 else 99  # 99: leader outside the config
+            tf, li = int(rng.integers(1, 30)), 0
+            li = tf + int(rng.integers(0, 40))
+            rng_state[g] = [self_id, tf, li]
+            script.append("leader %d %d %d %d" % (g, self_id, tf, li))
+            if self_id in m.active[g]:
+                m.active[g][self_id] = True
+        else:
+            script.append("follower %d" % g)
+        c = int(rng.integers(0, 20))
+        committed[g] = c
+        script.append("setcommitted %d %d" % (g, c))
+
+    def tick():
+        for _ in range(5 * G):
+            g = int(rng.integers(0, G))
+            i = int(rng.choice(pool))
+            op = rng.random()
+            if op < 0.1 and rng_state[g]:
+                rng_state[g][2] += int(rng.integers(0, 5))
+                script.append("appended %d %d" % (g, rng_state[g][2]))
+                continue
+            typ = 4 if op < 0.7 else 9
+            rej = int(rng.random() < 0.1)
+            ctx = int(rng.random() < 0.5)
+            top = rng_state[g][2] if rng_state[g] else 30
+            idx = int(rng.integers(0, top + 1))
+            script.append("step %d %d %d %d %d %d" % (g, i, typ, idx, rej, ctx))
+            if i not in m.match[g]:
+                want.append("dropped")
+                continue
+            m.active[g][i] = True
+            if typ == 4 and not rej:
+                m.ack(g, i, idx)
+            if typ == 9 and ctx:
+                m.acks[g].add(i)
+        script.append("maybecommit")
+        adv = []
+        for g in range(G):
+            mci = m.committed(oracle, g)
+            st = rng_state[g]
+            if st and mci > committed[g] and st[1] <= mci <= st[2]:
+                committed[g] = mci
+                adv.append("advanced %d %d" % (g, mci))
+        want.extend(adv)
+        want.append("maybecommit-done %d" % len(adv))
+        for g in rng.choice(G, size=8, replace=False).tolist():
+            for i in sorted(m.match[g])[:3]:
+                script.append("hbcommit %d %d" % (g, i))
+                want.append("hbcommit %d %d %d" % (g, i, min(m.match[g][i], committed[g])))
+        script.append("ackquorum")
+        want.append("ackquorum " + "".join(str(m.ack_quorum(oracle, g)) for g in range(G)))
+
+    for rnd in range(6):
+        tick()
+        if rnd % 2 == 1:
+            script.append("checkquorum")
+            want.append("checkquorum " + "".join(str(m.quorum_active(oracle, g)) for g in range(G)))
+            for g in range(G):
+                self_id = rng_state[g][0] if rng_state[g] else None
+                for i in m.active[g]:
+                    if i != self_id:
+                        m.active[g][i] = False
+            script.append("quorumactive")  # what the next CheckQuorum would see with no traffic
+            want.append("quorumactive " + "".join(str(m.quorum_active(oracle, g)) for g in range(G)))
+    out = run_cli("\n".join(script) + "\n", timeout=300)
+    for k, (a, b) in enumerate(zip(out, want)):
+        assert a == b, (k, a, b)
+    assert len(out) == len(want)
+    assert any(l.startswith("advanced") for l in want)
