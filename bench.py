@@ -34,6 +34,7 @@ G_BATCH = 1 << 20
 VOTERS = 5
 BYTES_PER_GROUP = VOTERS * 8 + 8  # 5 Match loads + 1 commit store
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: 8.0 TB/s spec
+CPU_EXTRA = {}
 
 
 def splitmix_batch(seed, S, G):
@@ -57,6 +58,17 @@ def cpu_baseline(match, seconds=10.0):
             break
     ref = cb.out.copy()
     cb.close()
+    # two more CPU figures for context: the reference's own micro-benchmark shape
+    # (BASELINE cfg1, one thread, ns/op) and the best the host cores do on the engine's SoA layout
+    leaf_ns = oracle.bench_leaf_ns(VOTERS)
+    k, t1 = 0, time.perf_counter()
+    while time.perf_counter() - t1 < 2.0:
+        soa_out, soa_threads = oracle.bench_soa5(match, threads)
+        k += 1
+    soa_rate = k * match.shape[1] / (time.perf_counter() - t1)
+    assert np.array_equal(soa_out, ref)
+    CPU_EXTRA.update({"cpu_leaf_ns_per_op_voters5_1thread": round(leaf_ns, 2),
+                      "cpu_best_soa_groups_per_s": soa_rate, "cpu_best_soa_threads": soa_threads})
     return {
         "value": n * match.shape[1] / dt, "unit": "groups/s", "cores": int(used), "kind": "port",
         "sample": "%d passes over one 2^20-group x 5-voter dist-A batch (%.1f s wall, %d OpenMP threads), "
@@ -86,11 +98,20 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the engine has no CPU path)")
+    # Rehearsal on a one-GPU box (RAFTHIP_BENCH_REHEARSE=1): every rank drives cuda:0 and the
+    # collectives run over gloo on host tensors — the multi-rank control flow without RCCL.
+    rehearse = os.environ.get("RAFTHIP_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cdev = torch.device("cpu") if rehearse else dev  # where collective payloads live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     stream = torch.cuda.Stream(device=dev)
     engines = []
@@ -129,7 +150,7 @@ def main():
     gpu_ms = ev0.elapsed_time(ev1)
 
     if world > 1:
-        t = torch.tensor([wall, gpu_ms], dtype=torch.float64, device=dev)
+        t = torch.tensor([wall, gpu_ms], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall, gpu_ms = float(t[0]), float(t[1])
 
@@ -180,7 +201,7 @@ def main():
         a = time.perf_counter()
         pairs, n_changed = e0.commit_changed()
         b = time.perf_counter()
-        allp = multigpu.allgather_changed(pairs, rank * G_BATCH, dev if world > 1 else None)
+        allp = multigpu.allgather_changed(pairs, rank * G_BATCH, cdev if world > 1 else None)
         torch.cuda.synchronize()
         c = time.perf_counter()
     extra["commit_changed_ms"] = round(1e3 * (b - a), 3)
@@ -228,6 +249,7 @@ def main():
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"], _ = cpu_baseline(first_match)
+            out["extra"].update(CPU_EXTRA)
         print(json.dumps(out), flush=True)
 
     for e in engines:

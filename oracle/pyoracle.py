@@ -79,6 +79,10 @@ def lib():
         L.oracle_bench_create.argtypes = [C.c_uint64, C.c_int, vp, C.c_uint64]
         L.oracle_bench_run.restype = C.c_int
         L.oracle_bench_run.argtypes = [C.c_void_p, vp, C.c_int]
+        L.oracle_bench_leaf_ns.restype = C.c_double
+        L.oracle_bench_leaf_ns.argtypes = [C.c_int, C.c_uint64, C.c_uint64, u64p]
+        L.oracle_bench_soa5.restype = C.c_int
+        L.oracle_bench_soa5.argtypes = [C.c_uint64, vp, C.c_uint64, vp, C.c_int]
         L.oracle_bench_destroy.restype = None
         L.oracle_bench_destroy.argtypes = [C.c_void_p]
         _LIB = L
@@ -285,6 +289,21 @@ def batch_heartbeat_commit(match, committed):
     lib().oracle_batch_heartbeat_commit(G, S, _vp(match), match.strides[0] // 8,
                                         _vp(_chk(committed, np.uint64)), _vp(out), G)
     return out
+
+
+def bench_leaf_ns(voters, iters=20_000_000, seed=0x5EED0001):
+    """BenchmarkMajorityConfig_CommittedIndex/voters=V restated: ns per op, one thread."""
+    sink = C.c_uint64()
+    return float(lib().oracle_bench_leaf_ns(voters, iters, seed, C.byref(sink)))
+
+
+def bench_soa5(match, threads=0):
+    """Best-CPU figure: SoA planes + median-of-5 network on the host cores -> (out, threads used)."""
+    match = _chk(match, np.uint64)
+    assert match.shape[0] >= 5
+    out = np.empty(match.shape[1], dtype=np.uint64)
+    used = lib().oracle_bench_soa5(match.shape[1], _vp(match), match.strides[0] // 8, _vp(out), threads)
+    return out, int(used)
 
 
 class CpuBaseline:

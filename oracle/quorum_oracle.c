@@ -18,6 +18,7 @@
  * small open-addressing hash map, standing in for Go's map).
  */
 #include <stdint.h>
+#include <time.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -704,6 +705,71 @@ ORACLE_API int oracle_bench_run(void *h, uint64_t *out, int threads) {
     for (uint64_t g = 0; g < b->G; g++)
         out[g] = majority_committed_index(&b->cfg[g * (uint64_t)b->V], b->V, &b->l[g]);
 #endif
+    return used;
+}
+
+/*
+ * quorum/bench_test.go:24-40 as written: ONE MajorityConfig of V voters (ids
+ * 1..V) and one mapAckIndexer with rand.Int63n(MaxInt64)-style indexes,
+ * CommittedIndex called `iters` times on one thread.  Returns ns per op
+ * (BASELINE cfg1).  `sink` keeps the loop from being optimised away.
+ */
+ORACLE_API double oracle_bench_leaf_ns(int V, uint64_t iters, uint64_t seed, uint64_t *sink) {
+    uint64_t cfg[64];
+    idmap l;
+    idmap_init(&l, (uint32_t)V);
+    uint64_t x = seed;
+    for (int s = 0; s < V; s++) {
+        cfg[s] = (uint64_t)s + 1;
+        x += 0x9E3779B97F4A7C15ULL;
+        uint64_t z = x;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+        idmap_put(&l, cfg[s], ((z ^ (z >> 31)) >> 1) % 0x7FFFFFFFFFFFFFFFULL);
+    }
+    struct timespec t0, t1;
+    uint64_t acc = 0;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (uint64_t i = 0; i < iters; i++) {
+        acc += majority_committed_index(cfg, V, &l);
+        __asm__ volatile("" : "+r"(acc) : : "memory");
+    }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    idmap_free(&l);
+    *sink = acc;
+    return ((double)(t1.tv_sec - t0.tv_sec) * 1e9 + (double)(t1.tv_nsec - t0.tv_nsec)) / (double)iters;
+}
+
+/*
+ * "Best CPU" figure of SURVEY.md §8(d)(ii): NOT the reference's shape — the
+ * engine's own [slot][group] planes and a branch-free median network on the
+ * host cores — reported beside the port so the GPU/CPU ratio is not flattered
+ * by the map-shaped loop.  V = 5 only (the headline shape).
+ */
+ORACLE_API int oracle_bench_soa5(uint64_t G, const uint64_t *match, uint64_t stride, uint64_t *out,
+                                 int threads) {
+    int used = 1;
+#define ORACLE_CE(a, b) do { uint64_t lo_ = a < b ? a : b, hi_ = a < b ? b : a; a = lo_; b = hi_; } while (0)
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+#pragma omp parallel
+    {
+#pragma omp single
+        used = omp_get_num_threads();
+#pragma omp for schedule(static)
+#else
+    (void)threads;
+    {
+#endif
+        for (int64_t g = 0; g < (int64_t)G; g++) {
+            uint64_t a = match[g], b = match[stride + g], c = match[2 * stride + g],
+                     d = match[3 * stride + g], e = match[4 * stride + g];
+            ORACLE_CE(a, d); ORACLE_CE(b, e); ORACLE_CE(a, c); ORACLE_CE(b, d); ORACLE_CE(a, b);
+            ORACLE_CE(c, e); ORACLE_CE(b, c); ORACLE_CE(d, e); ORACLE_CE(c, d);
+            out[g] = c; /* srt[5-(5/2+1)] = srt[2] */
+        }
+    }
+#undef ORACLE_CE
     return used;
 }
 
