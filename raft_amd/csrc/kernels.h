@@ -118,6 +118,16 @@ __device__ __forceinline__ void sort_asc_batcher(u64 (&v)[N]) {
     batcher_impl<N>(v, std::make_integer_sequence<int, Batcher<N>::n>{});
 }
 
+// Minimal networks up to 8 keys, Batcher's above.
+template <int N>
+__device__ __forceinline__ void sort_keys(u64 (&v)[N]) {
+    if constexpr (N <= 8) {
+        sort_asc<N>(v);
+    } else {
+        sort_asc_batcher<N>(v);
+    }
+}
+
 // MajorityConfig.CommittedIndex for a config of exactly V voters held in v[]:
 // sort, take srt[n-(n/2+1)] — quorum/majority.go:165-171.
 template <int V>
@@ -137,7 +147,7 @@ __device__ __forceinline__ u64 committed_masked(const u64 (&v)[S], u32 m) {
     u64 a[S];
 #pragma unroll
     for (int s = 0; s < S; ++s) a[s] = ((m >> s) & 1u) ? v[s] : 0ull;
-    sort_asc<S>(a);
+    sort_keys<S>(a);
     const int n = __popc(m);
     const int pos = S - (n / 2 + 1);
     constexpr int kLo = S - (S / 2 + 1);  // smallest position any n can select
@@ -293,37 +303,45 @@ __global__ __launch_bounds__(kCommitBlock) void k_commit_uniform(const u64* __re
 }
 
 // ---------------------------------------------------------------------------
-// K2 — ProgressTracker.Committed with per-group joint configs, S <= 8 slots:
+// K2 — ProgressTracker.Committed with per-group joint configs, S <= 16 slots:
 // min(CommittedIndex(incoming), CommittedIndex(outgoing)), quorum/joint.go:49-56.
+// Both halves are sorted from the same loaded keys.  S <= 8: 512 lanes x 2
+// chunks and one mask byte per group; 9..16: 256 lanes x 1 chunk (4S VGPRs of
+// keys per lane) and 16-bit masks; a uniform config of more than 8 voters
+// (in_mask == NULL) runs here too.
 // ---------------------------------------------------------------------------
-template <int S, int MODE>
-__global__ __launch_bounds__(kCommitBlock) void k_commit_masked(const u64* __restrict__ match,
-                                                                u64 stride, u64 G,
-                                                                const uint8_t* __restrict__ in_mask,
-                                                                const uint8_t* __restrict__ out_mask,
-                                                                u64* __restrict__ commit, LogBounds lb,
-                                                                Pair* __restrict__ stage,
-                                                                u32* __restrict__ counts) {
-    const u64 base = (u64)blockIdx.x * kTileGroups + threadIdx.x * 2;
-    Vec<u64, 2> in[kCH][S];
-    Vec<uint8_t, 2> m0[kCH], m1[kCH];
+template <int S, typename MaskT, int MODE, int BLOCK, int CH>
+__global__ __launch_bounds__(BLOCK) void k_commit_masked(const u64* __restrict__ match, u64 stride, u64 G,
+                                                         const MaskT* __restrict__ in_mask,
+                                                         const MaskT* __restrict__ out_mask,
+                                                         u32 uniform_voters, u64* __restrict__ commit,
+                                                         LogBounds lb, Pair* __restrict__ stage,
+                                                         u32* __restrict__ counts) {
+    const u64 base = (u64)blockIdx.x * (BLOCK * 2 * CH) + threadIdx.x * 2;
+    Vec<u64, 2> in[CH][S];
+    Vec<MaskT, 2> m0[CH], m1[CH];
 #pragma unroll
-    for (int c = 0; c < kCH; ++c) {
-        const u64 g0 = base + (u64)c * kCommitBlock * 2;
+    for (int c = 0; c < CH; ++c) {
+        const u64 g0 = base + (u64)c * BLOCK * 2;
 #pragma unroll
         for (int s = 0; s < S; ++s) in[c][s] = load_stream<u64, 2>(match + (u64)s * stride + g0);
-        m0[c] = load_stream<uint8_t, 2>(in_mask + g0);
-        m1[c] = load_stream<uint8_t, 2>(out_mask + g0);
+        if (in_mask) {
+            m0[c] = load_stream<MaskT, 2>(in_mask + g0);
+            m1[c] = load_stream<MaskT, 2>(out_mask + g0);
+        } else {
+            m0[c].v[0] = m0[c].v[1] = (MaskT)((1u << uniform_voters) - 1u);
+            m1[c].v[0] = m1[c].v[1] = 0;
+        }
     }
     bool any_out = false;
 #pragma unroll
-    for (int c = 0; c < kCH; ++c) any_out |= (m1[c].v[0] | m1[c].v[1]) != 0;
+    for (int c = 0; c < CH; ++c) any_out |= (m1[c].v[0] | m1[c].v[1]) != 0;
     // Joint configs are transient (confchange.go:51-126); when no lane of the
     // wavefront holds one, the outgoing half is skipped for the whole wave.
     const bool wave_joint = __any(any_out);
-    Vec<u64, 2> res[kCH];
+    Vec<u64, 2> res[CH];
 #pragma unroll
-    for (int c = 0; c < kCH; ++c)
+    for (int c = 0; c < CH; ++c)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             u64 a[S];
@@ -336,8 +354,10 @@ __global__ __launch_bounds__(kCommitBlock) void k_commit_masked(const u64* __res
             }
             res[c].v[j] = r;
         }
-    finish_tile<kCH, kCommitBlock, MODE>(res, base, G, commit, lb, stage, counts);
+    finish_tile<CH, BLOCK, MODE>(res, base, G, commit, lb, stage, counts);
 }
+constexpr int kMidBlock = 256;                 // tile shape of K2 at 9..16 slots
+constexpr int kMidTileGroups = kMidBlock * 2;  // 512; divides kPlaneAlign
 
 // Tail of the one-group-per-lane kernels (block = kBlock lanes = 4 waves):
 // store / diff / term-guard as MODE says, with the same ordered in-block

@@ -150,11 +150,13 @@ int copy_rows(rafthip_engine* e, void* dst, u64 dst_stride_b, const void* src, u
 // ---- kernel dispatch -----------------------------------------------------
 
 
-// Lane-per-group sorting-network kernels K1 / K2 (tile = kTileGroups) vs the
-// one-group-per-lane wide kernels (tile = kBlock).
+// Lane-per-group sorting-network kernels K1 / K2 at <= 8 keys (tile =
+// kTileGroups), K2 at 9..16 (tile = kMidTileGroups), the one-group-per-lane wide
+// kernels above that (tile = kBlock).
 bool small_commit_path(const rafthip_engine* e) {
     return e->S <= 8 || (e->uniform && e->uniform_voters > 0 && e->uniform_voters <= 8);
 }
+bool mid_commit_path(const rafthip_engine* e) { return !small_commit_path(e) && e->S <= 16 && !e->wide_bitonic; }
 
 template <int MODE>
 int launch_commit(rafthip_engine* e, u32* block_groups) {
@@ -193,14 +195,33 @@ int launch_commit(rafthip_engine* e, u32* block_groups) {
             switch (e->S) {
 #define RAFTHIP_CASE_M(SS)                                                                         \
     case SS:                                                                                       \
-        hipLaunchKernelGGL((k_commit_masked<SS, MODE>), dim3(blocks), dim3(kCommitBlock), 0, st,      \
-                           e->match, e->stride, G, m0, m1, e->commit, lb, e->stage, e->counts);    \
+        hipLaunchKernelGGL((k_commit_masked<SS, uint8_t, MODE, kCommitBlock, kCH>), dim3(blocks),     \
+                           dim3(kCommitBlock), 0, st, e->match, e->stride, G, m0, m1, 0u, e->commit,  \
+                           lb, e->stage, e->counts);                                               \
         break;
                 RAFTHIP_CASE_M(1) RAFTHIP_CASE_M(2) RAFTHIP_CASE_M(3) RAFTHIP_CASE_M(4)
                 RAFTHIP_CASE_M(5) RAFTHIP_CASE_M(6) RAFTHIP_CASE_M(7) RAFTHIP_CASE_M(8)
 #undef RAFTHIP_CASE_M
                 default: return fail(RAFTHIP_EINVAL, "internal: slots %u", e->S);
             }
+        }
+    } else if (mid_commit_path(e)) {
+        const u32 blocks = (u32)((G + kMidTileGroups - 1) / kMidTileGroups);
+        *block_groups = kMidTileGroups;
+        if (CHANGED && blocks > e->counts_cap) return fail(RAFTHIP_EINVAL, "internal: counts capacity");
+        const uint16_t* m0 = uni ? nullptr : static_cast<const uint16_t*>(e->in_mask);
+        const uint16_t* m1 = uni ? nullptr : static_cast<const uint16_t*>(e->out_mask);
+        switch (e->S) {
+#define RAFTHIP_CASE_MM(SS)                                                                        \
+    case SS:                                                                                       \
+        hipLaunchKernelGGL((k_commit_masked<SS, uint16_t, MODE, kMidBlock, 1>), dim3(blocks),      \
+                           dim3(kMidBlock), 0, st, e->match, e->stride, G, m0, m1,                 \
+                           uni ? e->uniform_voters : 0u, e->commit, lb, e->stage, e->counts);      \
+        break;
+            RAFTHIP_CASE_MM(9) RAFTHIP_CASE_MM(10) RAFTHIP_CASE_MM(11) RAFTHIP_CASE_MM(12)
+            RAFTHIP_CASE_MM(13) RAFTHIP_CASE_MM(14) RAFTHIP_CASE_MM(15) RAFTHIP_CASE_MM(16)
+#undef RAFTHIP_CASE_MM
+            default: return fail(RAFTHIP_EINVAL, "internal: slots %u", e->S);
         }
     } else {
         const u32 blocks = (u32)((G + kBlock - 1) / kBlock);
@@ -230,11 +251,7 @@ int launch_commit(rafthip_engine* e, u32* block_groups) {
                        uni ? nullptr : static_cast<const MT*>(e->in_mask),                         \
                        uni ? nullptr : static_cast<const MT*>(e->out_mask), uv, e->commit, lb,     \
                        e->stage, e->counts)
-            if (e->S <= 12) {
-                RAFTHIP_REGS(12, uint16_t);
-            } else if (e->S <= 16) {
-                RAFTHIP_REGS(16, uint16_t);
-            } else if (e->S <= 24) {
+            if (e->S <= 24) {
                 RAFTHIP_REGS(24, uint32_t);
             } else if (e->S <= 32) {
                 RAFTHIP_REGS(32, uint32_t);

@@ -126,7 +126,8 @@ def main():
         m = rng.integers(0, 1 << 62, size=(Sw, G), dtype=np.uint64)
         mdt = gu.mask_dtype(Sw)
         full = mdt((1 << Sw) - 1 if Sw < 64 else gu.U64MAX)
-        for flags, kname in ((0, "k_commit_regs (K4r)"), (raft_amd.capi.FLAG_WIDE_BITONIC, "k_commit_wide bitonic (K4)")):
+        default = "k_commit_masked 256x1 (K2)" if Sw <= 16 else "k_commit_regs (K4r)"
+        for flags, kname in ((0, default), (raft_amd.capi.FLAG_WIDE_BITONIC, "k_commit_wide bitonic (K4)")):
             with raft_amd.Engine(G, Sw, stream=stream.cuda_stream, flags=flags) as e:
                 e.upload_config(np.full(G, full, dtype=mdt), np.zeros(G, dtype=mdt))
                 e.upload_match(m)
