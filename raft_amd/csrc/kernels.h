@@ -899,56 +899,97 @@ __device__ __forceinline__ int vote_joint(int r1, int r2) {
     return 1;
 }
 
+// A lane handles 4 consecutive groups: one dword per vote plane (256 B per wave
+// instruction instead of 64), masks as one 4-element vector, results as one
+// dword per output plane.
 template <typename MaskT>
 __global__ __launch_bounds__(kBlock) void k_tally_votes_wide(
-    const uint8_t* __restrict__ votes, u64 stride, u64 G, int S, const MaskT* __restrict__ in_mask,
+    const uint8_t* __restrict__ votes, u64 stride, int S, const MaskT* __restrict__ in_mask,
     const MaskT* __restrict__ out_mask, const MaskT* __restrict__ learner_mask, int uniform_voters,
     uint8_t* __restrict__ result, uint8_t* __restrict__ granted, uint8_t* __restrict__ rejected) {
-    const u64 g = (u64)blockIdx.x * kBlock + threadIdx.x;
-    if (g >= G) return;
+    const u64 g0 = ((u64)blockIdx.x * kBlock + threadIdx.x) * 4;  // < stride (multiple of 4096)
     const u64 slots = S >= 64 ? kU64Max : ((1ull << S) - 1ull);
-    u64 m0, m1, ml;
+    u64 m0[4], m1[4], ml[4];
     if (in_mask) {
-        m0 = (u64)in_mask[g] & slots;
-        m1 = (u64)out_mask[g] & slots;
-        ml = learner_mask ? (u64)learner_mask[g] : 0ull;
+        const Vec<MaskT, 4> a = load_vec<MaskT, 4>(in_mask + g0), b = load_vec<MaskT, 4>(out_mask + g0);
+        Vec<MaskT, 4> c;
+        if (learner_mask) c = load_vec<MaskT, 4>(learner_mask + g0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            m0[j] = (u64)a.v[j] & slots;
+            m1[j] = (u64)b.v[j] & slots;
+            ml[j] = learner_mask ? (u64)c.v[j] : 0ull;
+        }
     } else {
-        m0 = (uniform_voters >= 64 ? kU64Max : ((1ull << uniform_voters) - 1ull)) & slots;
-        m1 = 0;
-        ml = slots & ~m0;
+        const u64 vm = (uniform_voters >= 64 ? kU64Max : ((1ull << uniform_voters) - 1ull)) & slots;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            m0[j] = vm;
+            m1[j] = 0;
+            ml[j] = slots & ~vm;
+        }
     }
-    u64 yes = 0, no = 0;
+    u64 yes[4] = {0, 0, 0, 0}, no[4] = {0, 0, 0, 0};
     for (int s = 0; s < S; ++s) {
-        const u32 c = votes[(u64)s * stride + g];
-        yes |= (u64)(c == 2) << s;
-        no |= (u64)(c == 1) << s;
+        const u32 c = __builtin_nontemporal_load(reinterpret_cast<const u32*>(votes + (u64)s * stride + g0));
+        const u32 y = (c >> 1) & k01, n = c & ~(c >> 1) & k01;  // cell 2 = granted, 1 = rejected
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            yes[j] |= (u64)((y >> (8 * j)) & 1u) << s;
+            no[j] |= (u64)((n >> (8 * j)) & 1u) << s;
+        }
     }
-    result[g] = (uint8_t)vote_joint(vote_half(m0, yes, no), vote_half(m1, yes, no));
-    if (granted) granted[g] = (uint8_t)__popcll(yes & ~ml);
-    if (rejected) rejected[g] = (uint8_t)__popcll(no & ~ml);
+    u32 res = 0, gr = 0, rj = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        res |= (u32)vote_joint(vote_half(m0[j], yes[j], no[j]), vote_half(m1[j], yes[j], no[j])) << (8 * j);
+        gr |= (u32)__popcll(yes[j] & ~ml[j]) << (8 * j);  // tracker/tracker.go:274-287
+        rj |= (u32)__popcll(no[j] & ~ml[j]) << (8 * j);
+    }
+    *reinterpret_cast<u32*>(result + g0) = res;
+    if (granted) *reinterpret_cast<u32*>(granted + g0) = gr;
+    if (rejected) *reinterpret_cast<u32*>(rejected + g0) = rj;
 }
 
 template <typename MaskT, bool ACKS>
 __global__ __launch_bounds__(kBlock) void k_tally_bits_wide(
-    MaskT* __restrict__ bits, u64 G, int S, const MaskT* __restrict__ in_mask,
+    MaskT* __restrict__ bits, int S, const MaskT* __restrict__ in_mask,
     const MaskT* __restrict__ out_mask, const MaskT* __restrict__ learner_mask, int uniform_voters,
     uint8_t* __restrict__ out, const MaskT* __restrict__ keep) {
-    const u64 g = (u64)blockIdx.x * kBlock + threadIdx.x;
-    if (g >= G) return;
+    const u64 g0 = ((u64)blockIdx.x * kBlock + threadIdx.x) * 4;  // 4 groups per lane; < stride
     const u64 slots = S >= 64 ? kU64Max : ((1ull << S) - 1ull);
-    u64 m0, m1, yes = (u64)bits[g];
+    const Vec<MaskT, 4> B = load_vec<MaskT, 4>(bits + g0);
+    Vec<MaskT, 4> M0, M1, ML, K;
+    const bool lrn = !ACKS && in_mask && learner_mask;
     if (in_mask) {
-        m0 = (u64)in_mask[g] & slots;
-        m1 = (u64)out_mask[g] & slots;
-        if (!ACKS && learner_mask) yes &= ~(u64)learner_mask[g];
-    } else {
-        m0 = (uniform_voters >= 64 ? kU64Max : ((1ull << uniform_voters) - 1ull)) & slots;
-        m1 = 0;
+        M0 = load_vec<MaskT, 4>(in_mask + g0);
+        M1 = load_vec<MaskT, 4>(out_mask + g0);
+        if (lrn) ML = load_vec<MaskT, 4>(learner_mask + g0);
     }
-    const u64 no = ACKS ? 0ull : ~yes;
-    const int r = vote_joint(vote_half(m0, yes, no), vote_half(m1, yes, no));
-    out[g] = ACKS ? (uint8_t)r : (uint8_t)(r == 3);
-    if (keep) bits[g] = bits[g] & keep[g];
+    if (keep) K = load_vec<MaskT, 4>(keep + g0);
+    u32 res = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        u64 m0, m1, yes = (u64)B.v[j];
+        if (in_mask) {
+            m0 = (u64)M0.v[j] & slots;
+            m1 = (u64)M1.v[j] & slots;
+            if (lrn) yes &= ~(u64)ML.v[j];  // learners cast no vote (tracker.go:220-222)
+        } else {
+            m0 = (uniform_voters >= 64 ? kU64Max : ((1ull << uniform_voters) - 1ull)) & slots;
+            m1 = 0;
+        }
+        const u64 no = ACKS ? 0ull : ~yes;
+        const int r = vote_joint(vote_half(m0, yes, no), vote_half(m1, yes, no));
+        res |= (u32)(ACKS ? r : (r == 3)) << (8 * j);
+    }
+    *reinterpret_cast<u32*>(out + g0) = res;
+    if (keep) {
+        Vec<MaskT, 4> nb;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) nb.v[j] = B.v[j] & K.v[j];
+        store_vec<MaskT, 4>(bits + g0, nb);
+    }
 }
 
 }  // namespace rafthip

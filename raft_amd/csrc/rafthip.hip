@@ -320,10 +320,10 @@ static int tally_bits(rafthip_engine* e, void* bits, uint8_t*& out, const char* 
                            uni ? nullptr : static_cast<const uint8_t*>(e->learner_mask), e->S,
                            e->uniform_voters, out, static_cast<const uint8_t*>(keep));
     } else {
-        const u32 blocks = (u32)((e->G + kBlock - 1) / kBlock);
+        const u32 blocks = (u32)((e->G + (u64)kBlock * 4 - 1) / ((u64)kBlock * 4));
 #define RAFTHIP_BW(MT)                                                                              \
     hipLaunchKernelGGL((k_tally_bits_wide<MT, ACKS>), dim3(blocks), dim3(kBlock), 0, st,            \
-                       static_cast<MT*>(bits), e->G, (int)e->S,                                     \
+                       static_cast<MT*>(bits), (int)e->S,                                           \
                        uni ? nullptr : static_cast<const MT*>(e->in_mask),                          \
                        uni ? nullptr : static_cast<const MT*>(e->out_mask),                         \
                        uni ? nullptr : static_cast<const MT*>(e->learner_mask),                     \
@@ -858,12 +858,15 @@ int rafthip_tally_votes(rafthip_engine* e) {
     if (e->uniform && e->uniform_voters == 0 && (rc = ensure_masks(e))) return rc;
     const bool uni = e->uniform && e->uniform_voters > 0;
     hipStream_t st = e->stream;
-    if (e->S <= 8) {
+    // A uniform config of <= 8 voters only needs its voter planes (the other rows
+    // are learners: no vote, no count), whatever S is: the 8-slot kernel at S := V.
+    const bool small = e->S <= 8 || (uni && e->uniform_voters <= 8);
+    if (small) {
         const u32 blocks = (u32)((e->G + (u64)kBlock * 16 - 1) / ((u64)kBlock * 16));
         const uint8_t* m0 = uni ? nullptr : static_cast<const uint8_t*>(e->in_mask);
         const uint8_t* m1 = uni ? nullptr : static_cast<const uint8_t*>(e->out_mask);
         const uint8_t* ml = uni ? nullptr : static_cast<const uint8_t*>(e->learner_mask);
-        switch (e->S) {
+        switch (e->S <= 8 ? e->S : e->uniform_voters) {
 #define RAFTHIP_CASE_T(SS)                                                                          \
     case SS:                                                                                        \
         hipLaunchKernelGGL((k_tally_votes_small<SS>), dim3(blocks), dim3(kBlock), 0, st, e->votes,   \
@@ -875,10 +878,10 @@ int rafthip_tally_votes(rafthip_engine* e) {
 #undef RAFTHIP_CASE_T
         }
     } else {
-        const u32 blocks = (u32)((e->G + kBlock - 1) / kBlock);
+        const u32 blocks = (u32)((e->G + (u64)kBlock * 4 - 1) / ((u64)kBlock * 4));
 #define RAFTHIP_TW(MT)                                                                               \
     hipLaunchKernelGGL((k_tally_votes_wide<MT>), dim3(blocks), dim3(kBlock), 0, st, e->votes, e->stride, \
-                       e->G, (int)e->S, uni ? nullptr : static_cast<const MT*>(e->in_mask),          \
+                       (int)e->S, uni ? nullptr : static_cast<const MT*>(e->in_mask),                \
                        uni ? nullptr : static_cast<const MT*>(e->out_mask),                          \
                        uni ? nullptr : static_cast<const MT*>(e->learner_mask),                      \
                        (int)e->uniform_voters, e->vote_result, e->granted, e->rejected)

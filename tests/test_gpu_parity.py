@@ -194,7 +194,7 @@ def test_empty_config_commits_infinity():
         assert (e.read_commit() == np.uint64(gu.U64MAX)).all()
 
 
-@pytest.mark.parametrize("S", [3, 5, 8, 12, 40, 64])
+@pytest.mark.parametrize("S", [3, 5, 8, 9, 10, 12, 16, 17, 33, 40, 64])
 def test_tallies_random(oracle, S):
     rng = np.random.default_rng(400 + S)
     G = 50021 if S <= 8 else 5003

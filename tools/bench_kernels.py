@@ -157,6 +157,27 @@ def main():
         timed("k_tally_votes_small<5> masked joint (K3)", "group", G, 5 + 3 + 3, e.tally_votes)
     del votes, bits
 
+    # ---- tallies on more than 8 slots (7 voters + 2 learners; 16 slots masked) ------------------
+    for Sw, uniform in ((9, True), (16, False)):
+        G = (1 << 24) >> sh
+        rng = np.random.default_rng(40 + Sw)
+        mdt = gu.mask_dtype(Sw)
+        votes = lut[rng.integers(0, 5, size=(Sw, G), dtype=np.uint8)]
+        bits = rng.integers(0, 1 << Sw, size=G).astype(mdt)
+        with raft_amd.Engine(G, Sw, stream=stream.cuda_stream) as e:
+            if uniform:
+                e.set_uniform_config(7)
+                tag, vb = "uniform 7 voters", 7 + 3
+            else:
+                full = mdt((1 << Sw) - 1)
+                e.upload_config(np.full(G, full, dtype=mdt), np.full(G, full >> mdt(1), dtype=mdt), np.zeros(G, dtype=mdt))
+                tag, vb = "masked joint", Sw + 3 + 3 * mdt().itemsize
+            e.upload_votes(votes)
+            e.upload_active(bits)
+            timed("tally_votes S=%d %s (K3 wide)" % (Sw, tag), "group", G, vb, e.tally_votes)
+            timed("quorum_active S=%d %s (K3 wide)" % (Sw, tag), "group", G, 1 + mdt().itemsize * (1 if uniform else 4), e.quorum_active)
+        del votes, bits
+
     # ---- cfg5: ack scatter / message ingest, 7 voters + 2 learners ---------------------------
     G = (1 << 22) >> sh
     Sv = 9
