@@ -124,8 +124,8 @@ int ensure(rafthip_engine* e, T*& p, size_t bytes, bool zero = true) {
     if (p) return RAFTHIP_OK;
     void* q = nullptr;
     HIP_TRY(hipMalloc(&q, bytes));
+    p = static_cast<T*>(q);  // owned by the engine from here on (freed by rafthip_destroy)
     if (zero) HIP_TRY(hipMemsetAsync(q, 0, bytes, e->stream));
-    p = static_cast<T*>(q);
     return RAFTHIP_OK;
 }
 

@@ -377,3 +377,38 @@ def test_full_size_properties(oracle):
             e.scatter_acks(recs)
             e.commit()
             assert (e.read_commit() >= base).all(), name
+
+
+def test_device_pointers_and_zero_copy_planes(oracle):
+    """`src`/`dst` may be device memory, and a host that fills planes on the GPU
+    itself can write them in place (rafthip_plane)."""
+    import torch
+    rng = np.random.default_rng(77)
+    S, G = 5, 70001
+    match = rand_match(rng, S, G)
+    m0, m1 = rand_masks(rng, S, G)
+    want = oracle.batch_committed(match, m0, m1)
+    # stateless entry point, every buffer on the device
+    dm = torch.from_numpy(match.view(np.int64)).cuda()
+    d0, d1 = torch.from_numpy(m0).cuda(), torch.from_numpy(m1).cuda()
+    dout = torch.empty(G, dtype=torch.int64, device="cuda")
+    L = raft_amd.load_library()
+    rc = L.rafthip_batch_committed_index(0, G, S, dm.data_ptr(), d0.data_ptr(), d1.data_ptr(), dout.data_ptr())
+    assert rc == 0, L.rafthip_last_error()
+    assert np.array_equal(dout.cpu().numpy().view(np.uint64), want)
+    # zero-copy: write the engine's own Match plane from a torch kernel, read commit in place
+    with raft_amd.Engine(G, S) as e:
+        e.upload_config(m0, m1)
+        ptr, stride = e.plane(raft_amd.capi.PLANE_MATCH)
+        assert stride >= G and stride % 4096 == 0
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        for s in range(S):
+            row = dm[s].contiguous()
+            assert hip.hipMemcpy(ctypes.c_void_p(ptr + 8 * s * stride), ctypes.c_void_p(row.data_ptr()),
+                                 ctypes.c_size_t(8 * G), 3) == 0  # hipMemcpyDeviceToDevice
+        e.commit()
+        e.synchronize()
+        cptr, _ = e.plane(raft_amd.capi.PLANE_COMMIT)
+        assert hip.hipMemcpy(ctypes.c_void_p(dout.data_ptr()), ctypes.c_void_p(cptr), ctypes.c_size_t(8 * G), 3) == 0
+        assert np.array_equal(dout.cpu().numpy().view(np.uint64), want)
