@@ -247,7 +247,7 @@ def main():
             },
             "extra": extra,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
             out["cpu_baseline"], _ = cpu_baseline(first_match)
             out["extra"].update(CPU_EXTRA)
         print(json.dumps(out), flush=True)
