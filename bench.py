@@ -187,6 +187,18 @@ def main():
         ev3.synchronize()
     extra["same_batch_avg_launch_us"] = round(1e3 * ev2.elapsed_time(ev3) / 500, 3)
 
+    # the stateless entry point (what quorum.BatchCommittedIndex binds to): host planes in, host
+    # result out, engine created and destroyed per call — the PCIe-inclusive rate, never `value`
+    if rank == 0:
+        full = np.full(G_BATCH, (1 << VOTERS) - 1, dtype=np.uint8)
+        raft_amd.batch_committed_index(first_match, full, device=local_rank)
+        a = time.perf_counter()
+        for _ in range(3):
+            one = raft_amd.batch_committed_index(first_match, full, device=local_rank)
+        extra["oneshot_host_buffers_groups_per_s"] = 3 * G_BATCH / (time.perf_counter() - a)
+        if not np.array_equal(one[idx], want):
+            raise SystemExit("bench: one-shot result differs from the oracle")
+
     # the one exchange step: changed (group, commit) pairs -> every rank
     from raft_amd import multigpu
     with torch.cuda.stream(stream):
