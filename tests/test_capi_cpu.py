@@ -64,3 +64,44 @@ def test_product_never_touches_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp", "Makefile")):
                 txt = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "oracle" not in txt.lower(), (dirpath, f)
+
+
+def test_create_validates_its_config_before_touching_a_device():
+    """Misuse is an error return with a message, never an abort (the reference panics)."""
+    import ctypes as C
+    L = raft_amd.load_library()
+    h = C.c_void_p()
+
+    def create(size=None, groups=16, slots=3, flags=0):
+        cfg = capi._Config(C.sizeof(capi._Config) if size is None else size, 0, groups, slots, flags, None)
+        rc = L.rafthip_create(C.byref(cfg), C.byref(h))
+        return rc, L.rafthip_last_error().decode()
+
+    for kw, word in ((dict(size=8), "struct_size"), (dict(groups=0), "num_groups"),
+                     (dict(groups=1 << 32), "32-bit group id"), (dict(slots=0), "num_slots"),
+                     (dict(slots=65), "num_slots"), (dict(flags=2), "flags")):
+        rc, msg = create(**kw)
+        assert rc == -22 and word in msg, (kw, rc, msg)
+        assert h.value is None
+    # NULL engine on every entry point that takes one
+    for name in ("rafthip_synchronize", "rafthip_tally_votes", "rafthip_quorum_active", "rafthip_ack_quorum",
+                 "rafthip_check_quorum"):
+        assert getattr(L, name)(None) == -22, name
+    assert L.rafthip_mask_bytes(None) == -22
+    assert L.rafthip_destroy(None) == 0  # like free(NULL)
+    n = C.c_uint64(7)
+    assert L.rafthip_commit_changed(None, None, 0, C.byref(n)) == -22
+    assert L.rafthip_commit_advance(None, None, 0, C.byref(n)) == -22
+    assert L.rafthip_ingest_msgs(None, None, 0) == -22
+    assert L.rafthip_batch_committed_index(0, 4, 3, None, None, None, None) == -22
+
+
+def test_header_is_plain_c():
+    """The boundary is a C ABI: the header must compile as C99 on its own."""
+    import subprocess
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "t.c")
+        open(src, "w").write('#include "rafthip.h"\nint main(void) { return (int)sizeof(rafthip_msg) - 16; }\n')
+        subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I" + os.path.join(ROOT, "include"),
+                               "-c", src, "-o", os.path.join(d, "t.o")])
