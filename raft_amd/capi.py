@@ -246,6 +246,14 @@ class Engine:
                                               C.byref(n)))
         return out[:min(n.value, max_pairs)], n.value
 
+    def commit_report_into(self, dst, max_pairs, advance=False):
+        """commit_changed / commit_advance with the pairs landing at `dst` (host or device
+        address, room for max_pairs pairs).  Returns the total number of pairs."""
+        n = C.c_uint64()
+        fn = self._L.rafthip_commit_advance if advance else self._L.rafthip_commit_changed
+        _check(fn(self._h, _ptr(dst) if max_pairs else None, max_pairs, C.byref(n)))
+        return n.value
+
     def commit_advance(self, max_pairs=None):
         """raft.maybeCommit for every group. Returns (pairs[PAIR_DTYPE], n_advanced)."""
         if max_pairs is None:

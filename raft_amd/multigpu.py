@@ -44,6 +44,26 @@ def route_acks(recs, total_groups, world):
     return out
 
 
+def _allgather_pairs(buf, n, world, group):
+    """buf: int64 tensor holding n (group, commit) pairs as 2n words, on the device
+    the process group communicates on.  Count all-gather, then one padded payload
+    all-gather; returns the concatenation over ranks as numpy PAIR_DTYPE."""
+    import torch
+    import torch.distributed as dist
+
+    dev = buf.device
+    counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(counts, torch.tensor([n], dtype=torch.int64, device=dev), group=group)
+    counts = [int(c.item()) for c in counts]
+    width = max(max(counts), 1)
+    send = buf[: 2 * width] if buf.numel() >= 2 * width else torch.cat(
+        [buf[: 2 * n], torch.zeros(2 * width - 2 * n, dtype=torch.int64, device=dev)])
+    outs = [torch.empty(width * 2, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(outs, send.contiguous(), group=group)
+    parts = [o[: 2 * c].cpu().numpy().view(PAIR_DTYPE) for o, c in zip(outs, counts)]
+    return np.concatenate(parts)
+
+
 def allgather_changed(pairs, group_base=0, device=None, group=None):
     """All-gather changed pairs across ranks.
 
@@ -59,17 +79,28 @@ def allgather_changed(pairs, group_base=0, device=None, group=None):
     local["group"] += np.uint64(group_base)
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return local
-    world = dist.get_world_size(group)
     dev = device if device is not None else torch.device("cpu")
-    n = torch.tensor([len(local)], dtype=torch.int64, device=dev)
-    counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(counts, n, group=group)
-    counts = [int(c.item()) for c in counts]
-    width = max(max(counts), 1)
-    buf = torch.zeros(width * 2, dtype=torch.int64, device=dev)
-    if len(local):
-        buf[: 2 * len(local)] = torch.from_numpy(local.view(np.int64).reshape(-1).copy()).to(dev)
-    outs = [torch.empty(width * 2, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(outs, buf, group=group)
-    parts = [o[: 2 * c].cpu().numpy().view(PAIR_DTYPE) for o, c in zip(outs, counts)]
-    return np.concatenate(parts) if parts else local[:0]
+    buf = torch.from_numpy(local.view(np.int64).reshape(-1).copy()).to(dev)
+    return _allgather_pairs(buf, len(local), dist.get_world_size(group), group)
+
+
+def commit_changed_allgather(engine, group_base=0, device=None, group=None, max_pairs=None, advance=False):
+    """The path's one exchange step, without a host hop in the middle: the engine's
+    commit pass (rafthip_commit_changed, or rafthip_commit_advance with
+    advance=True) packs its pairs straight into a tensor on `device` (the GPU for
+    RCCL; host memory for gloo), group ids are rebased there, and the tensor is
+    all-gathered.  Returns (all pairs as numpy PAIR_DTYPE sorted by global group id,
+    this rank's pair count)."""
+    import torch
+    import torch.distributed as dist
+
+    cap = engine.G if max_pairs is None else max_pairs
+    dev = device if device is not None else torch.device("cpu")
+    buf = torch.empty(2 * max(cap, 1), dtype=torch.int64, device=dev)
+    n_total = engine.commit_report_into(buf.data_ptr(), cap, advance=advance)
+    n = min(n_total, cap)
+    if n:
+        buf[0:2 * n:2] += group_base
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return buf[: 2 * n].cpu().numpy().view(PAIR_DTYPE), n_total
+    return _allgather_pairs(buf, n, dist.get_world_size(group), group), n_total

@@ -52,6 +52,20 @@ def _free_port():
     return p
 
 
+class _FakeEngine:
+    """Stands in for raft_amd.Engine on a GPU-less host: hands out prepared pairs the
+    way rafthip_commit_changed does (up to max_pairs copied to dst, total returned)."""
+
+    def __init__(self, G, pairs):
+        self.G, self.pairs = G, np.ascontiguousarray(pairs)
+
+    def commit_report_into(self, dst, max_pairs, advance=False):
+        import ctypes
+        n = min(len(self.pairs), max_pairs)
+        ctypes.memmove(dst, self.pairs.ctypes.data, n * PAIR_DTYPE.itemsize)
+        return len(self.pairs)
+
+
 def _worker(rank, world, port, total, q):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -66,7 +80,12 @@ def _worker(rank, world, port, total, q):
         pairs = np.zeros(n, dtype=PAIR_DTYPE)
         pairs["group"] = local_groups
         pairs["commit"] = (local_groups + first) * 3 + rnd  # a function of the GLOBAL id
-        allp = multigpu.allgather_changed(pairs, first)
+        if rnd == 0:
+            allp = multigpu.allgather_changed(pairs, first)
+        else:
+            # the engine-fed form bench.py uses: pairs land in the collective's own buffer
+            allp, n_local = multigpu.commit_changed_allgather(_FakeEngine(count, pairs), first)
+            assert n_local == n
         q.put((rank, rnd, n, allp.tobytes()))
     dist.barrier()
     dist.destroy_process_group()
