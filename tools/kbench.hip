@@ -79,6 +79,50 @@ __global__ __launch_bounds__(BLOCK) void kv(const u64* __restrict__ match, u64 s
     }
 }
 
+// Buffer-instruction form with explicit cache-policy bits (aux: 1 = sc0, 2 = nt,
+// 16 = sc1) and an optional XCD-chunked tile order: workgroup b runs on XCD b % 8,
+// so tile = (b % 8) * (tiles / 8) + b / 8 gives every XCD one contiguous eighth.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+template <int V, int AUXL, int AUXS, bool XCD>
+__global__ __launch_bounds__(512) void kb(const u64* __restrict__ match, u64 stride, u64 G,
+                                          u64* __restrict__ commit, u64 tiles) {
+    constexpr int CH = 2, BLOCK = 512;
+    u64 tile = blockIdx.x;
+    if (XCD && tiles % 8 == 0) tile = (u64)(blockIdx.x % 8) * (tiles / 8) + blockIdx.x / 8;
+    const u64 tbase = tile * (u64)(BLOCK * 2 * CH);
+    const u32 voff = threadIdx.x * 16;
+    u32x4 in[CH][V];
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+#pragma unroll
+        for (int s = 0; s < V; ++s) {
+            const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)(match + (u64)s * stride + tbase + (u64)c * BLOCK * 2), 0, BLOCK * 16, 0x00020000);
+            in[c][s] = __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, AUXL);
+        }
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        u32x4 res;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            u64 a[V];
+#pragma unroll
+            for (int s = 0; s < V; ++s) a[s] = ((u64)in[c][s][2 * j + 1] << 32) | in[c][s][2 * j];
+            const u64 r = committed_fixed<V>(a);
+            res[2 * j] = (u32)r;
+            res[2 * j + 1] = (u32)(r >> 32);
+        }
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(commit + tbase + (u64)c * BLOCK * 2), 0, BLOCK * 16, 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b128(res, r, voff, 0, AUXS);
+    }
+}
+template <int V, int AUXL, int AUXS, bool XCD>
+void launch_kb(const u64* m, u64 stride, u64 G, u64* c, hipStream_t st) {
+    const u64 tiles = (G + 2047) / 2048;
+    hipLaunchKernelGGL((kb<V, AUXL, AUXS, XCD>), dim3((unsigned)tiles), dim3(512), 0, st, m, stride, G, c, tiles);
+}
+
 struct Variant {
     std::string name;
     void (*launch)(const u64*, u64, u64, u64*, hipStream_t);
@@ -133,6 +177,15 @@ int main(int argc, char** argv) {
         {"ch4_b64_nt", launch_kv<V, 4, 64, 1, false, 0>},
         {"ch2_b512_nt_p2", launch_kv<V, 2, 512, 1, false, 2>},
         {"SUM_ch2_b256_nt", launch_kv<V, 2, 256, 1, true, 0>},
+        {"buf_plain", launch_kb<V, 0, 0, false>},
+        {"buf_nt_nt", launch_kb<V, 2, 2, false>},
+        {"buf_nt_nt_xcd", launch_kb<V, 2, 2, true>},
+        {"buf_sc1_nt", launch_kb<V, 16, 2, false>},
+        {"buf_sc1nt_nt", launch_kb<V, 18, 2, false>},
+        {"buf_sc0sc1nt_nt", launch_kb<V, 19, 2, false>},
+        {"buf_nt_sc1nt", launch_kb<V, 2, 18, false>},
+        {"buf_nt_sc0sc1nt", launch_kb<V, 2, 19, false>},
+        {"buf_nt_plain_xcd", launch_kb<V, 2, 0, true>},
     };
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
