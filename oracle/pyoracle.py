@@ -79,6 +79,8 @@ def lib():
         L.oracle_bench_create.argtypes = [C.c_uint64, C.c_int, vp, C.c_uint64]
         L.oracle_bench_run.restype = C.c_int
         L.oracle_bench_run.argtypes = [C.c_void_p, vp, C.c_int]
+        L.oracle_selfcheck_committed.restype = C.c_uint64
+        L.oracle_selfcheck_committed.argtypes = [C.c_uint64, C.c_uint64]
         L.oracle_bench_leaf_ns.restype = C.c_double
         L.oracle_bench_leaf_ns.argtypes = [C.c_int, C.c_uint64, C.c_uint64, u64p]
         L.oracle_bench_soa5.restype = C.c_int
@@ -289,6 +291,11 @@ def batch_heartbeat_commit(match, committed):
     lib().oracle_batch_heartbeat_commit(G, S, _vp(match), match.strides[0] // 8,
                                         _vp(_chk(committed, np.uint64)), _vp(out), G)
     return out
+
+
+def selfcheck_committed(cases, seed=0x5EED):
+    """Main vs alternative CommittedIndex on `cases` random inputs, in C. Returns #mismatches."""
+    return int(lib().oracle_selfcheck_committed(cases, seed))
 
 
 def bench_leaf_ns(voters, iters=20_000_000, seed=0x5EED0001):

@@ -282,6 +282,61 @@ ORACLE_API uint64_t oracle_log_maybe_commit(uint64_t committed, uint64_t max_ind
     return committed;
 }
 
+/*
+ * Differential self-check in the spirit of quorum/quick_test.go:28-64, at a
+ * volume the Python loop cannot reach: `cases` random (config, indexer) pairs,
+ * CommittedIndex against the reference's own alternative algorithm
+ * (quick_test.go:85-122).  Generators: up to 64 voters, ids from a small pool
+ * (so config and indexer overlap only partly: missing ids), and index values
+ * that are small with many ties, zero, or full-range including >= 2^63.
+ * Returns the number of mismatches.
+ */
+ORACLE_API uint64_t oracle_selfcheck_committed(uint64_t cases, uint64_t seed) {
+    uint64_t bad = 0;
+#ifdef _OPENMP
+#pragma omp parallel for reduction(+ : bad) schedule(static)
+#endif
+    for (int64_t c = 0; c < (int64_t)cases; c++) {
+        uint64_t x = seed + (uint64_t)c * 0x9E3779B97F4A7C15ULL;
+#define ORACLE_NEXT(dst) do { x += 0x9E3779B97F4A7C15ULL; uint64_t z_ = x; \
+        z_ = (z_ ^ (z_ >> 30)) * 0xBF58476D1CE4E5B9ULL; z_ = (z_ ^ (z_ >> 27)) * 0x94D049BB133111EBULL; \
+        dst = z_ ^ (z_ >> 31); } while (0)
+        uint64_t r;
+        ORACLE_NEXT(r);
+        int wide = (r & 15) == 0;
+        int n = (int)((r >> 8) % (wide ? 65 : 10)); /* mostly <= 9 ids like the reference, sometimes up to 64 */
+        int pool = n + 1 + (int)((r >> 20) % 8);
+        uint64_t cfg[64], ids[80], vals[80];
+        uint64_t used = 0, used_hi = 0; /* pool <= 72 */
+        int k = 0;
+        while (k < n) {
+            ORACLE_NEXT(r);
+            int id = (int)(r % (uint64_t)pool);
+            uint64_t *w = id < 64 ? &used : &used_hi;
+            uint64_t bit = 1ULL << (id & 63);
+            if (*w & bit) continue;
+            *w |= bit;
+            cfg[k++] = (uint64_t)id + 1;
+        }
+        int ln = 0;
+        for (int id = 0; id < pool; id++) {
+            ORACLE_NEXT(r);
+            if ((r & 3) == 0) continue; /* not in the indexer */
+            ids[ln] = (uint64_t)id + 1;
+            uint64_t kind = (r >> 2) & 7, v;
+            ORACLE_NEXT(v);
+            vals[ln] = kind < 4 ? v % (uint64_t)(n + 1) : kind == 4 ? 0 : kind == 5 ? (v | (1ULL << 63)) : v;
+            ln++;
+        }
+#undef ORACLE_NEXT
+        idmap l;
+        build_map(&l, ids, vals, ln);
+        if (majority_committed_index(cfg, n, &l) != alt_majority_committed_index(cfg, n, &l)) bad++;
+        idmap_free(&l);
+    }
+    return bad;
+}
+
 /* ------------------------------------------------------------------------ */
 /* Batched SoA views.  The engine's layout is [slot][group] planes plus two  */
 /* per-group slot bitmasks (incoming = Voters[0], outgoing = Voters[1]).     */

@@ -71,6 +71,13 @@ def test_quick_vs_alternative(oracle):
         assert oracle.majority_committed_index(c, l) == oracle.alt_majority_committed_index(c, l)
 
 
+def test_ten_million_random_cases_vs_alternative(oracle):
+    """The same differential at volume (SURVEY.md §8c plan: >= 10^7 cases), with
+    edge generators the reference's quick test lacks: up to 64 voters, ids missing
+    from the indexer, zeros, ties, values >= 2^63."""
+    assert oracle.selfcheck_committed(10_000_000) == 0
+
+
 def test_batch_views_match_golden(oracle):
     """The SoA views the GPU tests compare against reproduce the goldens too."""
     for swap in (False, True):
