@@ -899,56 +899,88 @@ __device__ __forceinline__ int vote_joint(int r1, int r2) {
     return 1;
 }
 
-// A lane handles 4 consecutive groups: one dword per vote plane (256 B per wave
-// instruction instead of 64), masks as one 4-element vector, results as one
-// dword per output plane.
+// A lane handles 4*NW consecutive groups: one NW-dword vector per vote plane,
+// masks as 4-element vectors, results as one NW-dword vector per output plane.
+// Eight slots at a time: bit b of byte j of ay[q] = "slot 8w+b granted in group
+// 4q+j", so a slot costs two shift-ors per four groups; the bytes are spread into
+// the per-group 64-bit sets once per eight slots.
+constexpr int kVoteWideNW = 4;  // 16 groups per lane: 16-B loads per vote plane
 template <typename MaskT>
 __global__ __launch_bounds__(kBlock) void k_tally_votes_wide(
     const uint8_t* __restrict__ votes, u64 stride, int S, const MaskT* __restrict__ in_mask,
     const MaskT* __restrict__ out_mask, const MaskT* __restrict__ learner_mask, int uniform_voters,
     uint8_t* __restrict__ result, uint8_t* __restrict__ granted, uint8_t* __restrict__ rejected) {
-    const u64 g0 = ((u64)blockIdx.x * kBlock + threadIdx.x) * 4;  // < stride (multiple of 4096)
+    constexpr int NW = kVoteWideNW;
+    const u64 g0 = ((u64)blockIdx.x * kBlock + threadIdx.x) * (4 * NW);  // < stride (multiple of 4096)
     const u64 slots = S >= 64 ? kU64Max : ((1ull << S) - 1ull);
-    u64 m0[4], m1[4], ml[4];
-    if (in_mask) {
-        const Vec<MaskT, 4> a = load_vec<MaskT, 4>(in_mask + g0), b = load_vec<MaskT, 4>(out_mask + g0);
-        Vec<MaskT, 4> c;
-        if (learner_mask) c = load_vec<MaskT, 4>(learner_mask + g0);
+    u64 yes[NW][4], no[NW][4];
+#pragma unroll
+    for (int q = 0; q < NW; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) yes[q][j] = no[q][j] = 0;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+        if (w * 8 >= S) break;  // wave-uniform
+        u32 ay[NW], an[NW];
+#pragma unroll
+        for (int q = 0; q < NW; ++q) ay[q] = an[q] = 0;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const int s = w * 8 + b;
+            if (s < S) {
+                const Vec<u32, NW> c = load_stream<u32, NW>(reinterpret_cast<const u32*>(votes + (u64)s * stride + g0));
+#pragma unroll
+                for (int q = 0; q < NW; ++q) {
+                    ay[q] |= ((c.v[q] >> 1) & k01) << b;               // cell 2 = granted
+                    an[q] |= (c.v[q] & ~(c.v[q] >> 1) & k01) << b;      // cell 1 = rejected
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NW; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                yes[q][j] |= (u64)((ay[q] >> (8 * j)) & 0xFFu) << (8 * w);
+                no[q][j] |= (u64)((an[q] >> (8 * j)) & 0xFFu) << (8 * w);
+            }
+    }
+    Vec<u32, NW> res, gr, rj;
+#pragma unroll
+    for (int q = 0; q < NW; ++q) {
+        u64 m0[4], m1[4], ml[4];
+        if (in_mask) {
+            const Vec<MaskT, 4> a = load_vec<MaskT, 4>(in_mask + g0 + 4 * q), b = load_vec<MaskT, 4>(out_mask + g0 + 4 * q);
+            Vec<MaskT, 4> c;
+            if (learner_mask) c = load_vec<MaskT, 4>(learner_mask + g0 + 4 * q);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                m0[j] = (u64)a.v[j] & slots;
+                m1[j] = (u64)b.v[j] & slots;
+                ml[j] = learner_mask ? (u64)c.v[j] : 0ull;
+            }
+        } else {
+            const u64 vm = (uniform_voters >= 64 ? kU64Max : ((1ull << uniform_voters) - 1ull)) & slots;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                m0[j] = vm;
+                m1[j] = 0;
+                ml[j] = slots & ~vm;
+            }
+        }
+        u32 r = 0, g = 0, x = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            m0[j] = (u64)a.v[j] & slots;
-            m1[j] = (u64)b.v[j] & slots;
-            ml[j] = learner_mask ? (u64)c.v[j] : 0ull;
+            r |= (u32)vote_joint(vote_half(m0[j], yes[q][j], no[q][j]), vote_half(m1[j], yes[q][j], no[q][j])) << (8 * j);
+            g |= (u32)__popcll(yes[q][j] & ~ml[j]) << (8 * j);  // tracker/tracker.go:274-287
+            x |= (u32)__popcll(no[q][j] & ~ml[j]) << (8 * j);
         }
-    } else {
-        const u64 vm = (uniform_voters >= 64 ? kU64Max : ((1ull << uniform_voters) - 1ull)) & slots;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            m0[j] = vm;
-            m1[j] = 0;
-            ml[j] = slots & ~vm;
-        }
+        res.v[q] = r;
+        gr.v[q] = g;
+        rj.v[q] = x;
     }
-    u64 yes[4] = {0, 0, 0, 0}, no[4] = {0, 0, 0, 0};
-    for (int s = 0; s < S; ++s) {
-        const u32 c = __builtin_nontemporal_load(reinterpret_cast<const u32*>(votes + (u64)s * stride + g0));
-        const u32 y = (c >> 1) & k01, n = c & ~(c >> 1) & k01;  // cell 2 = granted, 1 = rejected
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            yes[j] |= (u64)((y >> (8 * j)) & 1u) << s;
-            no[j] |= (u64)((n >> (8 * j)) & 1u) << s;
-        }
-    }
-    u32 res = 0, gr = 0, rj = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        res |= (u32)vote_joint(vote_half(m0[j], yes[j], no[j]), vote_half(m1[j], yes[j], no[j])) << (8 * j);
-        gr |= (u32)__popcll(yes[j] & ~ml[j]) << (8 * j);  // tracker/tracker.go:274-287
-        rj |= (u32)__popcll(no[j] & ~ml[j]) << (8 * j);
-    }
-    *reinterpret_cast<u32*>(result + g0) = res;
-    if (granted) *reinterpret_cast<u32*>(granted + g0) = gr;
-    if (rejected) *reinterpret_cast<u32*>(rejected + g0) = rj;
+    store_vec<u32, NW>(reinterpret_cast<u32*>(result + g0), res);
+    if (granted) store_vec<u32, NW>(reinterpret_cast<u32*>(granted + g0), gr);
+    if (rejected) store_vec<u32, NW>(reinterpret_cast<u32*>(rejected + g0), rj);
 }
 
 template <typename MaskT, bool ACKS>

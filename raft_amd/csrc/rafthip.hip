@@ -878,7 +878,8 @@ int rafthip_tally_votes(rafthip_engine* e) {
 #undef RAFTHIP_CASE_T
         }
     } else {
-        const u32 blocks = (u32)((e->G + (u64)kBlock * 4 - 1) / ((u64)kBlock * 4));
+        const u64 per = (u64)kBlock * 4 * kVoteWideNW;  // 4096 groups per workgroup = one plane granule
+        const u32 blocks = (u32)((e->G + per - 1) / per);
 #define RAFTHIP_TW(MT)                                                                               \
     hipLaunchKernelGGL((k_tally_votes_wide<MT>), dim3(blocks), dim3(kBlock), 0, st, e->votes, e->stride, \
                        (int)e->S, uni ? nullptr : static_cast<const MT*>(e->in_mask),                \
