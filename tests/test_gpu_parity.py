@@ -412,3 +412,34 @@ def test_device_pointers_and_zero_copy_planes(oracle):
         cptr, _ = e.plane(raft_amd.capi.PLANE_COMMIT)
         assert hip.hipMemcpy(ctypes.c_void_p(dout.data_ptr()), ctypes.c_void_p(cptr), ctypes.c_size_t(8 * G), 3) == 0
         assert np.array_equal(dout.cpu().numpy().view(np.uint64), want)
+
+
+def test_two_engines_from_two_threads(oracle):
+    """Different engines may be driven from different threads (include/rafthip.h
+    conventions); each thread's last-error text is its own."""
+    import threading
+    errs = []
+
+    def worker(seed, S):
+        try:
+            rng = np.random.default_rng(seed)
+            G = 20000 + seed
+            with raft_amd.Engine(G, S) as e:
+                e.set_uniform_config(S)
+                for _ in range(30):
+                    match = rand_match(rng, S, G)
+                    e.upload_match(match)
+                    e.commit()
+                    assert np.array_equal(e.read_commit(), oracle.batch_committed(match, uniform_voters=S))
+                    with pytest.raises(raft_amd.RafthipError) as ei:
+                        e.read_commit(G, 1)
+                    assert "[%d, +1)" % G in str(ei.value)
+        except BaseException as ex:  # noqa: BLE001 - reported to the main thread
+            errs.append(ex)
+
+    ts = [threading.Thread(target=worker, args=(i, s)) for i, s in enumerate((3, 5, 7, 12))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
