@@ -1,0 +1,160 @@
+"""Randomised sequences of C-ABI calls with random group ranges against a numpy
+shadow of every plane: after each compute call the engine's outputs must equal
+the oracle evaluated on the shadow.  Catches offset / stride / partial-range
+mistakes that whole-plane tests cannot."""
+import numpy as np
+import pytest
+
+import golden_util as gu
+import raft_amd
+from test_gpu_parity import rand_masks, rand_match
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("S,G,seed", [(1, 1, 0), (3, 5000, 1), (5, 4097, 2), (8, 12289, 3), (9, 3000, 4), (16, 2500, 5),
+                                      (17, 2049, 6), (40, 1500, 7), (64, 700, 8)])
+def test_random_call_sequences(oracle, S, G, seed):
+    rng = np.random.default_rng(9000 + seed)
+    mdt = gu.mask_dtype(S)
+    full = mdt((1 << S) - 1 if S < 64 else gu.U64MAX)
+    sh = dict(match=np.zeros((S, G), np.uint64), votes=np.zeros((S, G), np.uint8), commit=np.zeros(G, np.uint64),
+              m0=np.zeros(G, mdt), m1=np.zeros(G, mdt), ml=np.zeros(G, mdt), active=np.zeros(G, mdt),
+              acks=np.zeros(G, mdt), self=np.zeros(G, mdt), tf=np.zeros(G, np.uint64), tl=np.zeros(G, np.uint64))
+    checked = [0]
+    uniform = [0]  # current uniform voter count, or None when per-group masks are in force
+
+    def rng_range():
+        if rng.random() < 0.3:
+            return 0, G
+        a = int(rng.integers(0, G))
+        return a, int(rng.integers(0, G - a + 1))
+
+    def cfg_kw():
+        if uniform[0] is None:
+            return dict(in_mask=sh["m0"], out_mask=sh["m1"])
+        if uniform[0] == 0:  # both halves empty
+            return dict(in_mask=np.zeros(G, mdt), out_mask=np.zeros(G, mdt))
+        return dict(uniform_voters=uniform[0])
+
+    def lrn_kw():
+        kw = cfg_kw()
+        if uniform[0] is None:
+            kw["learner_mask"] = sh["ml"]
+        elif uniform[0] == 0:
+            kw["learner_mask"] = np.zeros(G, mdt)
+        return kw
+
+    with raft_amd.Engine(G, S) as e:
+        e.upload_active(sh["active"])
+        e.upload_acks(sh["acks"])
+        e.upload_self(sh["self"])
+        e.upload_term_range(sh["tf"], sh["tl"])
+        e.reset_votes()
+        for step in range(120):
+            op = int(rng.integers(0, 16))
+            checked[0] += op >= 10
+            a, n = rng_range()
+            if op == 0:
+                part = rand_match(rng, S, max(n, 1))[:, :n]
+                pad = np.zeros((S, n + 3), np.uint64)  # source rows wider than the range
+                pad[:, :n] = part
+                e.upload_match(pad, first=a, count=n, src_stride=n + 3)
+                sh["match"][:, a:a + n] = part
+            elif op == 1:
+                e.reset_match(a, n)
+                sh["match"][:, a:a + n] = 0
+            elif op == 2:
+                m0, m1 = rand_masks(rng, S, max(n, 1))
+                m0, m1 = m0[:n], m1[:n]
+                ml = (~(m0 | m1)) & full if rng.random() < 0.5 else None
+                if uniform[0] is not None:  # a partial upload materialises the uniform config for the rest
+                    v = uniform[0]
+                    vm = mdt(((1 << v) - 1) if v < 64 else gu.U64MAX) if v else mdt(0)
+                    sh["m0"][:], sh["m1"][:] = vm, 0
+                    sh["ml"][:] = (full & ~vm) if v else 0
+                e.upload_config(m0, m1, ml, first=a, count=n)
+                sh["m0"][a:a + n], sh["m1"][a:a + n] = m0, m1
+                sh["ml"][a:a + n] = ml if ml is not None else 0
+                uniform[0] = None
+            elif op == 3:
+                v = int(rng.integers(0, S + 1))
+                e.set_uniform_config(v)
+                uniform[0] = v
+            elif op == 4:
+                part = rng.integers(0, 3, size=(S, n)).astype(np.uint8)
+                e.upload_votes(np.ascontiguousarray(part), first=a, count=n, src_stride=n)
+                sh["votes"][:, a:a + n] = part
+            elif op == 5:
+                e.reset_votes(a, n)
+                sh["votes"][:, a:a + n] = 0
+            elif op in (6, 7, 8):
+                key = ("active", "acks", "self")[op - 6]
+                bits, _ = rand_masks(rng, S, max(n, 1), joint_frac=0, empty_frac=0.2)
+                bits = bits[:n]
+                if key == "self":
+                    bits = bits & (-bits.astype(np.int64)).astype(mdt)  # lowest set bit only
+                getattr(e, "upload_" + key)(np.ascontiguousarray(bits), first=a, count=n)
+                sh[key][a:a + n] = bits
+            elif op == 9:
+                k = int(rng.integers(0, 400))
+                msgs = np.zeros(k, dtype=raft_amd.MSG_DTYPE)
+                msgs["group"] = rng.integers(0, G + 2, size=k)
+                msgs["slot"] = rng.integers(0, min(S + 1, 255), size=k)
+                msgs["type"] = rng.choice(np.array([4, 9, 0xF0, 6], dtype=np.uint8), size=k)
+                msgs["reject"] = rng.random(k) < 0.2
+                msgs["flags"] = rng.integers(0, 2, size=k)
+                msgs["index"] = rng.integers(0, 50, size=k)
+                e.ingest_msgs(msgs)
+                oracle.step_leader_msgs(sh["match"], sh["active"], sh["acks"], sh["tl"], msgs)
+            elif op == 10:
+                e.commit()
+                sh["commit"] = oracle.batch_committed(sh["match"], **cfg_kw())
+                assert np.array_equal(e.read_commit(), sh["commit"]), step
+            elif op == 11:
+                pairs, cnt = e.commit_changed()
+                want = oracle.batch_committed(sh["match"], **cfg_kw())
+                ch = np.flatnonzero(want != sh["commit"])
+                assert cnt == len(ch) and np.array_equal(pairs["group"], ch.astype(np.uint64)), step
+                assert np.array_equal(pairs["commit"], want[ch]), step
+                sh["commit"] = want
+            elif op == 12:
+                tf = rng.integers(0, 10, size=n).astype(np.uint64)
+                tl = tf + rng.integers(0, 40, size=n).astype(np.uint64) - (rng.random(n) < 0.2)
+                e.upload_term_range(tf, np.ascontiguousarray(tl), first=a, count=n)
+                sh["tf"][a:a + n], sh["tl"][a:a + n] = tf, tl
+                com = rng.integers(0, 20, size=n).astype(np.uint64)
+                e.upload_commit(com, first=a, count=n)
+                sh["commit"][a:a + n] = com
+            elif op == 13:
+                pairs, cnt = e.commit_advance()
+                mci = oracle.batch_committed(sh["match"], **cfg_kw())
+                adv = (mci > sh["commit"]) & (mci >= sh["tf"]) & (mci <= sh["tl"])
+                idx = np.flatnonzero(adv)
+                assert cnt == len(idx) and np.array_equal(pairs["group"], idx.astype(np.uint64)), step
+                sh["commit"] = np.where(adv, mci, sh["commit"])
+                assert np.array_equal(e.read_commit(a, n), sh["commit"][a:a + n]), step
+                hb = e.heartbeat_commit(first=a, count=n)
+                assert np.array_equal(hb, np.minimum(sh["match"][:, a:a + n], sh["commit"][None, a:a + n])), step
+            elif op == 14:
+                e.tally_votes()
+                res, gr, rj = e.read_vote_result(a, n)
+                ores, ogr, orj = oracle.batch_tally_votes(sh["votes"], **lrn_kw())
+                assert np.array_equal(res, ores[a:a + n]), step
+                assert np.array_equal(gr, ogr[a:a + n]) and np.array_equal(rj, orj[a:a + n]), step
+                e.ack_quorum()
+                assert np.array_equal(e.read_ack_quorum(a, n),
+                                      oracle.batch_ack_quorum(sh["acks"], S, **cfg_kw())[a:a + n]), step
+            else:
+                if rng.random() < 0.5:
+                    e.quorum_active()
+                    want = oracle.batch_quorum_active(sh["active"], S, **lrn_kw())
+                else:
+                    e.check_quorum()
+                    want = oracle.batch_check_quorum(sh["active"], S, sh["self"], **lrn_kw())
+                assert np.array_equal(e.read_quorum_active(a, n), want[a:a + n]), step
+                assert np.array_equal(e.read_active(), sh["active"]), step
+        assert checked[0] >= 25
+        assert np.array_equal(e.read_match(), sh["match"])
+        assert np.array_equal(e.read_acks(), sh["acks"])
+        assert np.array_equal(e.read_term_range()[1], sh["tl"])
