@@ -254,6 +254,14 @@ int rafthip_commit_advance(rafthip_engine *e, rafthip_commit_pair *dst, uint64_t
                            uint64_t *n_advanced);
 int rafthip_read_commit(rafthip_engine *e, uint64_t first, uint64_t count, uint64_t *dst);
 
+/* raft.committedEntryInCurrentTerm for every group — raft.go:2001-2005: has the
+ * leader committed an entry of its own term (raftLog.committed inside
+ * [term_first, term_last])?  ReadIndex requests wait for it (raft.go:1312-1317,
+ * 2062-2071).  Output 1 / 0 per group; the commit plane must hold
+ * raftLog.committed (rafthip_commit_advance / rafthip_upload_commit). */
+int rafthip_committed_in_term(rafthip_engine *e);
+int rafthip_read_committed_in_term(rafthip_engine *e, uint64_t first, uint64_t count, uint8_t *dst);
+
 /* The commit index a heartbeat may carry to each peer — sendHeartbeat,
  * raft.go:669-685: min(Progress.Match, raftLog.committed) for every (slot,
  * group).  dst receives S rows of `count` values (row s at dst + s*dst_stride);

@@ -65,6 +65,9 @@ def lib():
         L.oracle_raftlog_maybe_commit.restype = C.c_int
         L.oracle_raftlog_maybe_commit.argtypes = [C.c_uint64, C.c_uint64, vp, C.c_uint64, u64p, C.c_uint64,
                                                   C.c_uint64]
+        L.oracle_committed_entry_in_current_term.restype = C.c_int
+        L.oracle_committed_entry_in_current_term.argtypes = [C.c_uint64, C.c_uint64, vp, C.c_uint64, C.c_uint64,
+                                                             C.c_uint64]
         L.oracle_batch_maybe_commit.restype = None
         L.oracle_batch_maybe_commit.argtypes = [C.c_uint64, C.c_int, vp, C.c_uint64, vp, vp, C.c_int, C.c_int,
                                                 vp, vp, vp, vp, vp, vp, vp]
@@ -241,6 +244,12 @@ def raftlog_maybe_commit(first_index, snap_term, terms, committed, max_index, te
     c = C.c_uint64(committed)
     ok = lib().oracle_raftlog_maybe_commit(first_index, snap_term, _vp(t), len(t), C.byref(c), max_index, term)
     return bool(ok), c.value
+
+
+def committed_entry_in_current_term(first_index, snap_term, terms, committed, term):
+    """raft.committedEntryInCurrentTerm on an explicit log."""
+    t = np.ascontiguousarray(np.asarray(terms, dtype=np.uint64))
+    return bool(lib().oracle_committed_entry_in_current_term(first_index, snap_term, _vp(t), len(t), committed, term))
 
 
 def batch_maybe_commit(match, logs, term, committed, in_mask=None, out_mask=None, uniform_voters=0):

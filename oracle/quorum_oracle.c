@@ -599,6 +599,14 @@ static int raftlog_maybe_commit(const oracle_log *l, uint64_t *committed, uint64
     return 0;
 }
 
+/* raft.go:2001-2005 — committedEntryInCurrentTerm on an explicit log. */
+ORACLE_API int oracle_committed_entry_in_current_term(uint64_t first_index, uint64_t snap_term,
+                                                      const uint64_t *terms, uint64_t n,
+                                                      uint64_t committed, uint64_t term) {
+    oracle_log l = {first_index, snap_term, terms, n};
+    return log_term_or_zero(&l, committed) == term;
+}
+
 ORACLE_API int oracle_raftlog_maybe_commit(uint64_t first_index, uint64_t snap_term,
                                            const uint64_t *terms, uint64_t n, uint64_t *committed,
                                            uint64_t max_index, uint64_t term) {

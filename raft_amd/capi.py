@@ -37,6 +37,7 @@ SYMBOLS = [
     "rafthip_ingest_msgs", "rafthip_commit_advance", "rafthip_upload_term_range",
     "rafthip_heartbeat_commit", "rafthip_upload_self", "rafthip_check_quorum",
     "rafthip_read_active", "rafthip_read_acks", "rafthip_read_term_range",
+    "rafthip_committed_in_term", "rafthip_read_committed_in_term",
 ]
 
 
@@ -113,6 +114,8 @@ def load_library():
         "rafthip_read_active": (i32, [vp, u64, u64, vp]),
         "rafthip_read_acks": (i32, [vp, u64, u64, vp]),
         "rafthip_read_term_range": (i32, [vp, u64, u64, vp, vp]),
+        "rafthip_committed_in_term": (i32, [vp]),
+        "rafthip_read_committed_in_term": (i32, [vp, u64, u64, vp]),
     }
     assert sorted(sig) == sorted(SYMBOLS)
     for name, (res, args) in sig.items():
@@ -283,6 +286,14 @@ class Engine:
         first, count = self._range(first, count)
         out = np.empty((self.S, count), dtype=np.uint64) if download else None
         _check(self._L.rafthip_heartbeat_commit(self._h, first, count, _ptr(out), count))
+        return out
+
+    def committed_in_term(self, first=0, count=None):
+        """raft.committedEntryInCurrentTerm for every group -> u8."""
+        first, count = self._range(first, count)
+        _check(self._L.rafthip_committed_in_term(self._h))
+        out = np.empty(count, dtype=np.uint8)
+        _check(self._L.rafthip_read_committed_in_term(self._h, first, count, _ptr(out)))
         return out
 
     def upload_self(self, bits, first=0, count=None):

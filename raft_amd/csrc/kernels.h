@@ -736,6 +736,25 @@ __global__ __launch_bounds__(kBlock) void k_heartbeat_commit(const u64* __restri
 }
 
 // ---------------------------------------------------------------------------
+// raft.committedEntryInCurrentTerm for every group — raft.go:2001-2005:
+// zeroTermOnOutOfBounds(term(raftLog.committed)) == r.Term, i.e. the committed
+// index lies in the run of entries that carry the leader's term (see kAdvance).
+// Gates ReadIndex (raft.go:1312-1317) and releasePendingReadIndexMessages.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_committed_in_term(const u64* __restrict__ commit,
+                                                              const u64* __restrict__ term_first,
+                                                              const u64* __restrict__ term_last,
+                                                              uint8_t* __restrict__ out) {
+    const u64 g0 = ((u64)blockIdx.x * kBlock + threadIdx.x) * 2;  // < stride (multiple of 4096)
+    const Vec<u64, 2> c = load_stream<u64, 2>(commit + g0), a = load_stream<u64, 2>(term_first + g0),
+                      b = load_stream<u64, 2>(term_last + g0);
+    Vec<uint8_t, 2> r;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) r.v[j] = (c.v[j] >= a.v[j] && c.v[j] <= b.v[j]) ? 1 : 0;
+    store_vec<uint8_t, 2>(out + g0, r);
+}
+
+// ---------------------------------------------------------------------------
 // K3 — tallies, S <= 8 (one mask byte per group).  A lane handles 16 groups:
 // one 16-byte load per plane, arithmetic done four groups at a time on the
 // bytes of a dword (counts never exceed 8, so bytes cannot carry).

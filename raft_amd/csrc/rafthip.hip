@@ -81,6 +81,7 @@ struct rafthip_engine {
     uint8_t* rejected = nullptr;
     uint8_t* qactive = nullptr;
     uint8_t* ack_result = nullptr;
+    uint8_t* in_term = nullptr;
 
     // changed-pair compaction
     Pair* stage = nullptr;
@@ -541,7 +542,7 @@ int rafthip_destroy(rafthip_engine* e) {
     void* bufs[] = {e->in_mask, e->out_mask,   e->learner_mask, e->match,    e->commit, e->votes,
                     e->active,  e->acks,       e->vote_result,  e->granted,  e->rejected, e->qactive,
                     e->ack_result, e->stage,   e->packed,       e->counts,   e->offsets,  e->ack_buf,
-                    e->d_rejected, e->self_mask, e->term_first, e->term_last, e->hb_commit};
+                    e->d_rejected, e->self_mask, e->term_first, e->term_last, e->hb_commit, e->in_term};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (e->h_scalar) (void)hipHostFree(e->h_scalar);
@@ -813,6 +814,31 @@ int rafthip_read_term_range(rafthip_engine* e, uint64_t first, uint64_t count, u
     if (term_last) HIP_TRY(hipMemcpyAsync(term_last, e->term_last + first, count * 8, hipMemcpyDefault, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     e->stats.bytes_downloaded += count * 8 * ((term_first ? 1 : 0) + (term_last ? 1 : 0));
+    return RAFTHIP_OK;
+}
+
+int rafthip_committed_in_term(rafthip_engine* e) {
+    if (!e) return fail(RAFTHIP_EINVAL, "engine is NULL");
+    DeviceGuard guard(e->device);
+    int rc;
+    if ((rc = ensure(e, e->term_first, (size_t)e->stride * sizeof(u64)))) return rc;
+    if ((rc = ensure(e, e->term_last, (size_t)e->stride * sizeof(u64)))) return rc;
+    if ((rc = ensure(e, e->in_term, e->stride))) return rc;
+    const u32 blocks = (u32)(e->stride / ((u64)kBlock * 2));
+    hipLaunchKernelGGL(k_committed_in_term, dim3(blocks), dim3(kBlock), 0, e->stream, e->commit, e->term_first,
+                       e->term_last, e->in_term);
+    HIP_TRY(hipGetLastError());
+    e->stats.groups_evaluated += e->G;
+    return RAFTHIP_OK;
+}
+
+int rafthip_read_committed_in_term(rafthip_engine* e, uint64_t first, uint64_t count, uint8_t* dst) {
+    int rc = check_range(e, first, count);
+    if (rc) return rc;
+    if (!dst) return fail(RAFTHIP_EINVAL, "dst is NULL");
+    DeviceGuard guard(e->device);
+    if ((rc = read_u8(e, e->in_term, "committed-in-term", first, count, dst))) return rc;
+    HIP_TRY(hipStreamSynchronize(e->stream));
     return RAFTHIP_OK;
 }
 

@@ -79,6 +79,27 @@ def test_commit_advance_random_logs(oracle, S, mode):
         assert e.stats()["advanced_reported"] == len(idx)
 
 
+def test_committed_entry_in_current_term(oracle):
+    """raft.go:2001-2005 against the literal term lookup on explicit logs."""
+    rng = np.random.default_rng(77)
+    G = 5000
+    logs = gu.random_logs(rng, G)
+    off, terms, first, snap = logs
+    term = rng.integers(0, 6, size=G).astype(np.uint64)
+    committed = np.maximum(first.astype(np.int64) - 2 + rng.integers(0, 16, size=G), 0).astype(np.uint64)
+    tf, tl = gu.term_range(off, terms, first, snap, term)
+    want = np.array([oracle.committed_entry_in_current_term(int(first[g]), int(snap[g]),
+                                                             terms[int(off[g]):int(off[g + 1])], int(committed[g]),
+                                                             int(term[g])) and int(term[g]) != 0
+                     for g in range(G)], dtype=np.uint8)
+    with raft_amd.Engine(G, 3) as e:
+        e.upload_commit(committed)
+        e.upload_term_range(tf, tl)
+        got = e.committed_in_term()
+        assert np.array_equal(got, want) and 0 < want.sum() < G
+        assert np.array_equal(e.committed_in_term(100, 50), want[100:150])
+
+
 def rand_msgs(rng, N, G, S, match=None):
     msgs = np.zeros(N, dtype=raft_amd.MSG_DTYPE)
     msgs["group"] = rng.integers(0, G, size=N)
