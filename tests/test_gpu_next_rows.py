@@ -239,3 +239,56 @@ def test_leader_tick_pipeline_full_size(oracle):
         assert np.array_equal(e.read_quorum_active(), want_qa)
         assert np.array_equal(e.read_active(), wa)
         assert 0.05 < want_qa.mean() < 1.0 and len(idx) > G // 10
+
+
+def test_scenario_fixtures_on_the_gpu():
+    """tests/golden/scenarios.json through the engine: one group per sequence, slot =
+    position of the id among voters + learners."""
+    import json
+    import os
+    with open(os.path.join(gu.HERE, "golden", "scenarios.json")) as fh:
+        sc = json.load(fh)
+    names = {"VotePending": 1, "VoteLost": 2, "VoteWon": 3}
+    for seq in sc["vote_sequences"]:
+        ids = seq["voters"]
+        with raft_amd.Engine(1, len(ids)) as e:
+            e.set_uniform_config(len(ids))
+            cells = np.zeros((len(ids), 1), dtype=np.uint8)
+            for st in seq["steps"]:
+                for i, v in st["record"]:
+                    if cells[ids.index(i), 0] == 0:
+                        cells[ids.index(i), 0] = 2 if v else 1
+                e.upload_votes(cells)
+                e.tally_votes()
+                res, gr, rj = e.read_vote_result()
+                assert (int(res[0]), int(gr[0]), int(rj[0])) == (names[st["result"]], st["granted"], st["rejected"]), (seq["src"], st)
+    for seq in sc["check_quorum_sequences"]:
+        ids = seq["voters"]
+        bit = lambda xs: np.array([sum(1 << ids.index(i) for i in xs)], dtype=np.uint8)
+        with raft_amd.Engine(1, len(ids)) as e:
+            e.set_uniform_config(len(ids))
+            e.upload_self(bit([seq["self"]]))
+            e.upload_active(bit([seq["self"]]))
+            for st in seq["steps"]:
+                if "active_before" in st:
+                    e.upload_active(bit(st["active_before"]))
+                msgs = np.zeros(len(st["heard_from"]), dtype=raft_amd.MSG_DTYPE)
+                msgs["slot"] = [ids.index(i) for i in st["heard_from"]]
+                msgs["type"] = raft_amd.MSG_HEARTBEAT_RESP
+                e.ingest_msgs(msgs)
+                e.check_quorum()
+                assert bool(e.read_quorum_active()[0]) == st["quorum_active"], (seq["src"], st)
+                assert int(e.read_active()[0]) == int(bit([seq["self"]])[0])
+    for seq in sc["read_index_sequences"]:
+        ids = seq["voters"] + seq.get("learners", [])
+        with raft_amd.Engine(1, len(ids)) as e:
+            e.set_uniform_config(len(seq["voters"]))
+            e.upload_acks(np.zeros(1, dtype=np.uint8))
+            for st in seq["steps"]:
+                msgs = np.zeros(len(st["acks"]), dtype=raft_amd.MSG_DTYPE)
+                msgs["slot"] = [ids.index(i) for i in st["acks"]]
+                msgs["type"] = raft_amd.MSG_HEARTBEAT_RESP
+                msgs["flags"] = raft_amd.MSGF_READ_CTX
+                e.ingest_msgs(msgs)
+                e.ack_quorum()
+                assert int(e.read_ack_quorum()[0]) == names[st["result"]], (seq["src"], st)

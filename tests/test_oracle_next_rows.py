@@ -98,3 +98,38 @@ def test_heartbeat_commit_is_min(oracle):
     match = np.array([[5, 0, 9], [7, 3, 1 << 63]], dtype=np.uint64)
     com = np.array([6, 2, 1 << 62], dtype=np.uint64)
     assert np.array_equal(oracle.batch_heartbeat_commit(match, com), np.minimum(match, com[None, :]))
+
+
+def _scenarios():
+    import json
+    import os
+    with open(os.path.join(gu.HERE, "golden", "scenarios.json")) as fh:
+        return json.load(fh)
+
+
+NAMES = {"VotePending": 1, "VoteLost": 2, "VoteWon": 3}
+
+
+def test_scenario_fixtures_on_the_oracle(oracle):
+    """tests/golden/scenarios.json: what the reference's state-machine tests state about
+    TallyVotes, MsgCheckQuorum and the ReadIndex ack quorum, on the id-level oracle."""
+    sc = _scenarios()
+    for seq in sc["vote_sequences"]:
+        votes = {}
+        for st in seq["steps"]:
+            for i, v in st["record"]:
+                votes.setdefault(i, v)  # RecordVote: first vote sticks (tracker.go:260-265)
+            assert oracle.majority_vote_result(seq["voters"], votes) == NAMES[st["result"]], (seq["src"], st)
+            assert sum(1 for v in votes.values() if v) == st["granted"]
+            assert sum(1 for v in votes.values() if not v) == st["rejected"]
+    for seq in sc["check_quorum_sequences"]:
+        active = set()
+        for st in seq["steps"]:
+            active |= set(st.get("active_before", [])) | set(st["heard_from"]) | {seq["self"]}
+            votes = {i: (i in active) for i in seq["voters"]}
+            assert (oracle.majority_vote_result(seq["voters"], votes) == 3) == st["quorum_active"], (seq["src"], st)
+            active = {seq["self"]}  # raft.go:1238-1242
+    for seq in sc["read_index_sequences"]:
+        for st in seq["steps"]:
+            acks = {i: True for i in st["acks"]}
+            assert oracle.majority_vote_result(seq["voters"], acks) == NAMES[st["result"]], (seq["src"], st)
