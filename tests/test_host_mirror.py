@@ -18,7 +18,9 @@ import pytest
 import golden_util as gu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CLI = os.path.join(ROOT, "raft_amd", "lib", "rafthost_cli")
+# RAFTHOST_CLI points the whole file at another build of the driver (e.g. the
+# AddressSanitizer one of tools/asan_host.sh)
+CLI = os.environ.get("RAFTHOST_CLI", os.path.join(ROOT, "raft_amd", "lib", "rafthost_cli"))
 CASES = gu.load_cases()
 NAMES = {1: "VotePending", 2: "VoteLost", 3: "VoteWon"}
 
