@@ -187,6 +187,22 @@ def main():
         ev3.synchronize()
     extra["same_batch_avg_launch_us"] = round(1e3 * ev2.elapsed_time(ev3) / 500, 3)
 
+    # on-box streaming ceiling: a device-to-device copy of 1 GiB, read + write bytes
+    if rank == 0:
+        a_t = torch.empty(1 << 28, dtype=torch.int32, device=dev)
+        b_t = torch.empty_like(a_t)
+        with torch.cuda.stream(stream):
+            for _ in range(3):
+                b_t.copy_(a_t)
+            ev4, ev5 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev4.record(stream)
+            for _ in range(10):
+                b_t.copy_(a_t)
+            ev5.record(stream)
+            ev5.synchronize()
+        extra["dtod_copy_GBs"] = round(10 * 2 * a_t.numel() * 4 / (ev4.elapsed_time(ev5) * 1e-3) / 1e9, 1)
+        del a_t, b_t
+
     # the stateless entry point (what quorum.BatchCommittedIndex binds to): host planes in, host
     # result out, engine created and destroyed per call — the PCIe-inclusive rate, never `value`
     if rank == 0:
@@ -256,6 +272,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "frac_of_dtod_copy": (achieved / extra["dtod_copy_GBs"]) if extra.get("dtod_copy_GBs") else None,
                 "kernel": "k_commit_uniform<5, kStore>", "bytes_per_group": BYTES_PER_GROUP,
                 "avg_launch_us": kernel_s * 1e6,
             },
