@@ -187,6 +187,30 @@ def main():
         ev3.synchronize()
     extra["same_batch_avg_launch_us"] = round(1e3 * ev2.elapsed_time(ev3) / 500, 3)
 
+    # HIP-graph-amortised launch (SURVEY.md §8d caveat): one rotation over all batches captured
+    # on the engine stream and replayed — the per-launch host cost is gone, what remains is the
+    # kernel plus the kernel-to-kernel boundary on the device
+    try:
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=stream):
+            for e in engines:
+                e.commit()
+        with torch.cuda.stream(stream):
+            for _ in range(5):
+                graph.replay()
+            ev6, ev7 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = max(1, 1200 // len(engines))
+            ev6.record(stream)
+            for _ in range(reps):
+                graph.replay()
+            ev7.record(stream)
+            ev7.synchronize()
+        extra["hip_graph_avg_launch_us"] = round(1e3 * ev6.elapsed_time(ev7) / (reps * len(engines)), 3)
+        del graph
+    except Exception as ex:  # capture is a measurement extra, never the headline
+        extra["hip_graph_avg_launch_us"] = None
+        extra["hip_graph_error"] = str(ex)[:200]
+
     # on-box streaming ceiling: a device-to-device copy of 1 GiB, read + write bytes
     if rank == 0:
         a_t = torch.empty(1 << 28, dtype=torch.int32, device=dev)

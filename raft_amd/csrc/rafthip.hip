@@ -42,6 +42,8 @@ int fail(int code, const char* fmt, ...) {
 
 u64 round_up(u64 x, u64 a) { return (x + a - 1) / a * a; }
 
+constexpr u64 kMaxRecordsPerLaunch = 1ull << 30;  // scatter / ingest records per kernel launch
+
 int mask_bytes_for(u32 S) { return S <= 8 ? 1 : S <= 16 ? 2 : S <= 32 ? 4 : 8; }
 
 }  // namespace
@@ -731,16 +733,18 @@ int rafthip_scatter_acks(rafthip_engine* e, const rafthip_ack* recs, uint64_t n)
     if (!e) return fail(RAFTHIP_EINVAL, "engine is NULL");
     if (n == 0) return RAFTHIP_OK;
     if (!recs) return fail(RAFTHIP_EINVAL, "recs is NULL");
-    if (n > 0xFFFFFFFFull * kBlock) return fail(RAFTHIP_EINVAL, "too many acks in one call");
     DeviceGuard guard(e->device);
     const void* d_recs = nullptr;
     bool staged = false;
     int rc = stage_records(e, recs, n, &d_recs, &staged);
     if (rc) return rc;
-    const u32 blocks = (u32)((n + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(k_scatter_acks, dim3(blocks), dim3(kBlock), 0, e->stream, e->match, e->stride, e->G,
-                       e->S, static_cast<const Ack*>(d_recs), (u64)n, e->d_rejected);
-    HIP_TRY(hipGetLastError());
+    for (u64 off = 0; off < n; off += kMaxRecordsPerLaunch) {  // a launch stays below 2^32 lanes
+        const u64 m = n - off < kMaxRecordsPerLaunch ? n - off : kMaxRecordsPerLaunch;
+        const u32 blocks = (u32)((m + kBlock - 1) / kBlock);
+        hipLaunchKernelGGL(k_scatter_acks, dim3(blocks), dim3(kBlock), 0, e->stream, e->match, e->stride, e->G,
+                           e->S, static_cast<const Ack*>(d_recs) + off, m, e->d_rejected);
+        HIP_TRY(hipGetLastError());
+    }
     if (staged) HIP_TRY(hipStreamSynchronize(e->stream));  // caller may reuse its host buffer
     e->stats.acks_applied += n;
     return RAFTHIP_OK;
@@ -750,7 +754,6 @@ int rafthip_ingest_msgs(rafthip_engine* e, const rafthip_msg* msgs, uint64_t n) 
     if (!e) return fail(RAFTHIP_EINVAL, "engine is NULL");
     if (n == 0) return RAFTHIP_OK;
     if (!msgs) return fail(RAFTHIP_EINVAL, "msgs is NULL");
-    if (n > 0xFFFFFFFFull * kBlock) return fail(RAFTHIP_EINVAL, "too many messages in one call");
     DeviceGuard guard(e->device);
     int rc;
     const size_t mb = (size_t)e->stride * e->mbytes;
@@ -761,11 +764,14 @@ int rafthip_ingest_msgs(rafthip_engine* e, const rafthip_msg* msgs, uint64_t n) 
     const void* d_recs = nullptr;
     bool staged = false;
     if ((rc = stage_records(e, msgs, n, &d_recs, &staged))) return rc;
-    const u32 blocks = (u32)((n + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(k_ingest_msgs, dim3(blocks), dim3(kBlock), 0, e->stream, e->match, e->stride, e->G,
-                       e->S, e->active, e->acks, e->mbytes, e->term_last, static_cast<const Msg*>(d_recs),
-                       (u64)n, e->d_rejected + 1);
-    HIP_TRY(hipGetLastError());
+    for (u64 off = 0; off < n; off += kMaxRecordsPerLaunch) {
+        const u64 m = n - off < kMaxRecordsPerLaunch ? n - off : kMaxRecordsPerLaunch;
+        const u32 blocks = (u32)((m + kBlock - 1) / kBlock);
+        hipLaunchKernelGGL(k_ingest_msgs, dim3(blocks), dim3(kBlock), 0, e->stream, e->match, e->stride, e->G,
+                           e->S, e->active, e->acks, e->mbytes, e->term_last,
+                           static_cast<const Msg*>(d_recs) + off, m, e->d_rejected + 1);
+        HIP_TRY(hipGetLastError());
+    }
     if (staged) HIP_TRY(hipStreamSynchronize(e->stream));
     e->stats.msgs_ingested += n;
     return RAFTHIP_OK;
