@@ -228,6 +228,53 @@ int rafthip_scatter_acks(rafthip_engine *e, const rafthip_ack *recs, uint64_t n)
  * Inflights, MaybeDecrTo on Reject) stay with the host. */
 int rafthip_ingest_msgs(rafthip_engine *e, const rafthip_msg *msgs, uint64_t n);
 
+/* ---- wire ingest: the same step from serialized raftpb.Message bytes ------ */
+
+/* The raft id behind each Progress row: ids[s*src_stride + g] is the key of
+ * tracker.ProgressMap (tracker/progress.go:263) that slot s of group first+g
+ * holds, 0 (raft.None) = empty slot.  The lookup `r.trk.Progress[m.From]` of
+ * raft.go:1327 runs against this table on the device. */
+int rafthip_upload_ids(rafthip_engine *e, uint64_t first, uint64_t count, const uint64_t *ids,
+                       uint64_t src_stride);
+/* r.Term of each group, for the term gate of raft.Step (raft.go:1051-1139). */
+int rafthip_upload_term(rafthip_engine *e, uint64_t first, uint64_t count, const uint64_t *term);
+/* The pending ReadIndex request context of each group (readOnly.pendingReadIndex
+ * key, read_only.go:29-37,68-76): ctx_len[g] bytes (0 = none pending, at most 8)
+ * held little-endian in ctx[g] (byte i of the context = bits 8i..8i+7). */
+int rafthip_upload_read_ctx(rafthip_engine *e, uint64_t first, uint64_t count, const uint64_t *ctx,
+                            const uint8_t *ctx_len);
+
+/* What happened to one serialized message (rafthip_ingest_wire). */
+#define RAFTHIP_WIRE_APPLIED 0     /* stepped as rafthip_ingest_msgs steps its record */
+#define RAFTHIP_WIRE_OTHER_TYPE 1  /* well-formed, not MsgAppResp / MsgHeartbeatResp: the host steps it */
+#define RAFTHIP_WIRE_NO_PROGRESS 2 /* no Progress for m.From: dropped, raft.go:1327-1331 */
+#define RAFTHIP_WIRE_STALE_TERM 3  /* m.Term < r.Term: ignored, raft.go:1087-1138 */
+#define RAFTHIP_WIRE_HIGHER_TERM 4 /* m.Term > r.Term: the host must step down (raft.go:1056-1085); not applied */
+#define RAFTHIP_WIRE_NESTED 5      /* carries a non-empty entries / snapshot / responses payload: the host
+                                      decodes it; not applied */
+#define RAFTHIP_WIRE_MALFORMED 6   /* Message.Unmarshal returns an error (raftpb/raft.pb.go:1801-2179) */
+#define RAFTHIP_WIRE_BAD_GROUP 7   /* envelope group id >= num_groups */
+#define RAFTHIP_WIRE_STATUSES 8
+#define RAFTHIP_MSGF_HAS_CTX 2     /* out record flag: Message.Context is non-empty */
+#define RAFTHIP_WIRE_NO_SLOT 0xFF  /* out record slot / type when unresolved / outside uint8 */
+
+/* Decode n gogo-protobuf serialized raftpb.Message values (raftpb/raft.proto:71-108,
+ * Unmarshal raftpb/raft.pb.go:1801-2179, skipRaft :3027-3104) and step the
+ * responses among them on the device: message i is bytes[offsets[i], offsets[i+1])
+ * and is addressed to group groups[i] (the multi-raft envelope; raftpb.Message
+ * carries no group id).  For MsgAppResp / MsgHeartbeatResp: the term gate of
+ * raft.Step (Term 0 = local, passes), the Progress lookup by m.From against the
+ * id table, then exactly rafthip_ingest_msgs' updates; a heartbeat response
+ * records a ReadIndex ack iff its Context equals the group's pending one.
+ * Everything else is classified, never applied.  out_msgs (decoded records,
+ * slot resolved), out_status (one RAFTHIP_WIRE_* per message) and
+ * status_counts[RAFTHIP_WIRE_STATUSES] may each be NULL; all pointers may be
+ * host or device memory except status_counts (host).  Requires
+ * rafthip_upload_ids and rafthip_upload_term. */
+int rafthip_ingest_wire(rafthip_engine *e, const uint8_t *bytes, const uint64_t *offsets,
+                        const uint32_t *groups, uint64_t n, rafthip_msg *out_msgs,
+                        uint8_t *out_status, uint64_t *status_counts);
+
 /* ProgressTracker.Committed for every group — tracker/tracker.go:179-181 =
  * JointConfig.CommittedIndex (quorum/joint.go:49-56) over
  * MajorityConfig.CommittedIndex (quorum/majority.go:126-172) with

@@ -74,6 +74,11 @@ def lib():
         L.oracle_step_leader_msgs.restype = None
         L.oracle_step_leader_msgs.argtypes = [C.c_uint64, C.c_int, vp, C.c_uint64, vp, vp, C.c_int, vp, vp,
                                               C.c_uint64, vp]
+        L.oracle_message_unmarshal.restype = C.c_int
+        L.oracle_message_unmarshal.argtypes = [vp, C.c_uint64, vp]
+        L.oracle_step_wire_msgs.restype = None
+        L.oracle_step_wire_msgs.argtypes = [C.c_uint64, C.c_int, vp, C.c_uint64, vp, vp, C.c_int, vp, C.c_uint64,
+                                            vp, vp, vp, vp, C.c_uint64, vp, vp, C.c_uint64, vp, vp, vp]
         L.oracle_batch_check_quorum.restype = None
         L.oracle_batch_check_quorum.argtypes = [C.c_uint64, C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp]
         L.oracle_batch_heartbeat_commit.restype = None
@@ -278,6 +283,51 @@ def step_leader_msgs(match, active, acks, last_index, msgs):
                                   active.dtype.itemsize, _vp(_chk(last_index, np.uint64)), _vp(msgs),
                                   len(msgs), _vp(counts))
     return int(counts[0]), int(counts[1])
+
+
+class _PbMsg(C.Structure):
+    _fields_ = [("type", C.c_int32), ("to", C.c_uint64), ("from_", C.c_uint64), ("term", C.c_uint64),
+                ("log_term", C.c_uint64), ("index", C.c_uint64), ("commit", C.c_uint64),
+                ("reject_hint", C.c_uint64), ("vote", C.c_uint64), ("reject", C.c_int), ("has_ctx", C.c_int),
+                ("ctx_off", C.c_uint64), ("ctx_len", C.c_uint64), ("nested", C.c_int)]
+
+
+def message_unmarshal(data):
+    """raftpb.Message.Unmarshal on `data` (bytes).  Returns (rc, fields): rc 0 = nil error, < 0 = the
+    error the reference returns; fields = dict of the scalar fields, context bytes (None = nil), and
+    `nested` (a non-empty entries / snapshot / responses payload was present, not decoded)."""
+    buf = np.frombuffer(bytes(data), dtype=np.uint8) if len(data) else np.zeros(0, dtype=np.uint8)
+    m = _PbMsg()
+    rc = int(lib().oracle_message_unmarshal(_vp(buf) if len(buf) else None, len(buf), C.byref(m)))
+    if rc:
+        return rc, None
+    ctx = bytes(buf[m.ctx_off:m.ctx_off + m.ctx_len]) if m.has_ctx else None
+    return 0, {"type": m.type, "to": m.to, "from": m.from_, "term": m.term, "logTerm": m.log_term, "index": m.index,
+               "commit": m.commit, "rejectHint": m.reject_hint, "vote": m.vote, "reject": bool(m.reject),
+               "context": ctx, "nested": bool(m.nested)}
+
+
+def step_wire_msgs(match, active, acks, ids, term, read_ctx, read_ctx_len, data, offsets, groups):
+    """Serialized raftpb.Message values stepped in order on a leader; mutates match/active/acks.
+    ids [S][G] = ProgressMap key per slot.  Returns (out_msgs, out_status, counts[8])."""
+    match = _chk(match, np.uint64)
+    ids = _chk(ids, np.uint64)
+    S, G = match.shape
+    assert ids.shape == (S, G)
+    offsets = _chk(np.ascontiguousarray(offsets), np.uint64)
+    groups = _chk(np.ascontiguousarray(groups), np.uint32)
+    n = len(groups)
+    assert len(offsets) == n + 1
+    data = _chk(np.ascontiguousarray(data), np.uint8)
+    out_msgs = np.zeros(n, dtype=MSG_DTYPE)
+    out_status = np.zeros(n, dtype=np.uint8)
+    counts = np.zeros(8, dtype=np.uint64)
+    lib().oracle_step_wire_msgs(G, S, _vp(match), match.strides[0] // 8, _vp(_chk(active)), _vp(_chk(acks)),
+                                active.dtype.itemsize, _vp(ids), ids.strides[0] // 8, _vp(_chk(term, np.uint64)),
+                                _vp(_chk(read_ctx, np.uint64)), _vp(_chk(read_ctx_len, np.uint8)),
+                                _vp(data) if len(data) else None, len(data), _vp(offsets), _vp(groups), n,
+                                _vp(out_msgs), _vp(out_status), _vp(counts))
+    return out_msgs, out_status, counts
 
 
 def batch_check_quorum(active, nslots, self_mask, in_mask=None, out_mask=None, learner_mask=None,

@@ -691,6 +691,211 @@ ORACLE_API void oracle_step_leader_msgs(uint64_t G, int nslots, uint64_t *match,
     }
 }
 
+/* ------------------------------------------------------------------------ */
+/* Serialized raftpb.Message -> stepLeader bookkeeping.                       */
+/* ------------------------------------------------------------------------ */
+
+/* What Message.Unmarshal (raftpb/raft.pb.go:1801-2179) leaves in the struct,
+ * as far as this path reads it.  Nested messages (entries :1944-1977,
+ * snapshot :1997-2032, responses :2125-2158) are only measured: a non-empty
+ * one sets nested, and the caller leaves the message to a full decoder. */
+typedef struct {
+    int32_t type;
+    uint64_t to, from, term, log_term, index, commit, reject_hint, vote;
+    int reject;
+    int has_ctx;          /* Context != nil */
+    uint64_t ctx_off, ctx_len;
+    int nested;
+} oracle_pbmsg;
+
+enum { PB_OK = 0, PB_EOF = -1, PB_OVERFLOW = -2, PB_BAD_LENGTH = -3, PB_BAD_WIRETYPE = -4,
+       PB_BAD_TAG = -5, PB_END_GROUP = -6 };
+
+/* The varint loop of every field (e.g. :1807-1820): shift >= 64 is checked
+ * before the read, so an 11th byte is an overflow; bits past 63 fall off. */
+static int pb_varint(const uint8_t *d, uint64_t l, uint64_t *i, uint64_t *v) {
+    *v = 0;
+    for (unsigned shift = 0;; shift += 7) {
+        if (shift >= 64) return PB_OVERFLOW;
+        if (*i >= l) return PB_EOF;
+        uint8_t b = d[(*i)++];
+        *v |= (uint64_t)(b & 0x7F) << shift;
+        if (b < 0x80) return PB_OK;
+    }
+}
+
+/* skipRaft, raft.pb.go:3027-3104: length of one field of any wire type at d[0..l). */
+static int pb_skip(const uint8_t *d, uint64_t l, int64_t *n) {
+    uint64_t i = 0;
+    int depth = 0, rc;
+    while (i < l) {
+        uint64_t wire, tmp;
+        if ((rc = pb_varint(d, l, &i, &wire))) return rc;
+        switch ((int)(wire & 7)) {
+        case 0:
+            if ((rc = pb_varint(d, l, &i, &tmp))) return rc;
+            break;
+        case 1: i += 8; break;
+        case 2:
+            if ((rc = pb_varint(d, l, &i, &tmp))) return rc;
+            if ((int64_t)tmp < 0) return PB_BAD_LENGTH;
+            i += tmp;
+            break;
+        case 3: depth++; break;
+        case 4:
+            if (depth == 0) return PB_END_GROUP;
+            depth--;
+            break;
+        case 5: i += 4; break;
+        default: return PB_BAD_WIRETYPE;
+        }
+        if ((int64_t)i < 0) return PB_BAD_LENGTH;
+        if (depth == 0) { *n = (int64_t)i; return PB_OK; }
+    }
+    return PB_EOF;
+}
+
+ORACLE_API int oracle_message_unmarshal(const uint8_t *d, uint64_t l, oracle_pbmsg *m) {
+    memset(m, 0, sizeof(*m));
+    uint64_t i = 0;
+    int rc;
+    while (i < l) {
+        uint64_t pre = i, wire, v;
+        if ((rc = pb_varint(d, l, &i, &wire))) return rc;
+        int32_t field = (int32_t)(wire >> 3);
+        int wt = (int)(wire & 7);
+        if (wt == 4) return PB_END_GROUP;
+        if (field <= 0) return PB_BAD_TAG;
+        switch (field) {
+        case 1: case 2: case 3: case 4: case 5: case 6: case 8: case 10: case 11: case 13:
+            if (wt != 0) return PB_BAD_WIRETYPE;
+            if ((rc = pb_varint(d, l, &i, &v))) return rc;
+            switch (field) {
+            case 1: m->type = (int32_t)v; break; /* MessageType is int32: shifts >= 32 contribute 0 */
+            case 2: m->to = v; break;
+            case 3: m->from = v; break;
+            case 4: m->term = v; break;
+            case 5: m->log_term = v; break;
+            case 6: m->index = v; break;
+            case 8: m->commit = v; break;
+            case 10: m->reject = v != 0; break;
+            case 11: m->reject_hint = v; break;
+            default: m->vote = v; break;
+            }
+            break;
+        case 7: case 9: case 12: case 14: {
+            if (wt != 2) return PB_BAD_WIRETYPE;
+            if ((rc = pb_varint(d, l, &i, &v))) return rc;
+            if ((int64_t)v < 0) return PB_BAD_LENGTH;
+            uint64_t post = i + v;
+            if ((int64_t)post < 0) return PB_BAD_LENGTH;
+            if (post > l) return PB_EOF;
+            if (field == 12) { /* :2101-2104: the last occurrence replaces the value; never nil afterwards */
+                m->has_ctx = 1;
+                m->ctx_off = i;
+                m->ctx_len = v;
+            } else if (v > 0) {
+                m->nested = 1;
+            }
+            i = post;
+            break;
+        }
+        default: {
+            int64_t skippy;
+            i = pre;
+            if ((rc = pb_skip(d + i, l - i, &skippy))) return rc;
+            if (skippy < 0 || (int64_t)(i + (uint64_t)skippy) < 0) return PB_BAD_LENGTH;
+            if (i + (uint64_t)skippy > l) return PB_EOF;
+            i += (uint64_t)skippy;
+        }
+        }
+    }
+    return PB_OK;
+}
+
+/*
+ * A batch of serialized messages stepped one at a time on a leader, message i
+ * addressed to group groups[i]:
+ *   Message.Unmarshal; an error -> status 6.  Types other than MsgAppResp (4)
+ *   and MsgHeartbeatResp (9) -> status 1 (not this path); a non-empty nested
+ *   payload -> status 5 (left to a full decoder).
+ *   raft.Step's term gate, raft.go:1051-1139: Term 0 is local; Term > r.Term
+ *   -> status 4 (becomeFollower: the host's business); Term < r.Term -> status 3.
+ *   stepLeader: no Progress for m.From -> status 2 (raft.go:1327-1331); else
+ *   RecentActive = true; MsgAppResp && !Reject: MaybeUpdate(Index) (:1477);
+ *   MsgHeartbeatResp with the pending ReadIndex context: recvAck (:1552,
+ *   read_only.go:68-76).
+ * ids is the ProgressMap key of each slot, [nslots][ids_stride], 0 = no row.
+ */
+ORACLE_API void oracle_step_wire_msgs(uint64_t G, int nslots, uint64_t *match, uint64_t stride,
+                                      void *active, void *acks, int mask_bytes, const uint64_t *ids,
+                                      uint64_t ids_stride, const uint64_t *term,
+                                      const uint64_t *read_ctx, const uint8_t *read_ctx_len,
+                                      const uint8_t *bytes, uint64_t nbytes, const uint64_t *offsets,
+                                      const uint32_t *groups, uint64_t n, oracle_msg *out_msgs,
+                                      uint8_t *out_status, uint64_t *counts) {
+    for (int k = 0; k < 8; k++) counts[k] = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        oracle_msg o = {groups[i], 0xFF, 0xFF, 0, 0, 0};
+        oracle_pbmsg m;
+        int st, decoded = 0;
+        uint64_t g = groups[i];
+        if (g >= G) {
+            st = 7;
+        } else if (!(offsets[i] <= offsets[i + 1] && offsets[i + 1] <= nbytes)) {
+            st = 6;
+        } else if (oracle_message_unmarshal(bytes + offsets[i], offsets[i + 1] - offsets[i], &m)) {
+            st = 6;
+        } else {
+            decoded = 1;
+            o.type = (uint32_t)m.type <= 0xFF ? (uint8_t)m.type : 0xFF;
+            o.reject = (uint8_t)m.reject;
+            o.index = m.index;
+            if (m.ctx_len > 0) o.flags |= 2;
+            if (m.type != 4 && m.type != 9) {
+                st = 1;
+            } else if (m.nested) {
+                st = 5;
+            } else if (m.term != 0 && m.term > term[g]) {
+                st = 4;
+            } else if (m.term != 0 && m.term < term[g]) {
+                st = 3;
+            } else {
+                int slot = -1;
+                for (int s = 0; s < nslots && slot < 0; s++) /* r.trk.Progress[m.From] */
+                    if (m.from != 0 && ids[(uint64_t)s * ids_stride + g] == m.from) slot = s;
+                if (slot < 0) {
+                    st = 2;
+                } else {
+                    st = 0;
+                    o.slot = (uint8_t)slot;
+                    store_mask(active, mask_bytes, g, load_mask(active, mask_bytes, g) | (1ULL << slot));
+                    if (m.type == 4) {
+                        if (!m.reject) {
+                            uint64_t next = 0;
+                            oracle_maybe_update(&match[(uint64_t)slot * stride + g], &next, m.index);
+                        }
+                    } else if (read_ctx_len[g] != 0 && m.ctx_len == read_ctx_len[g]) {
+                        /* pendingReadIndex[string(m.Context)] — the one request tracked per group */
+                        uint64_t want = read_ctx[g];
+                        int same = 1;
+                        for (uint64_t b = 0; b < m.ctx_len; b++)
+                            if (bytes[offsets[i] + m.ctx_off + b] != (uint8_t)(want >> (8 * b))) same = 0;
+                        if (same) {
+                            o.flags |= 1;
+                            store_mask(acks, mask_bytes, g, load_mask(acks, mask_bytes, g) | (1ULL << slot));
+                        }
+                    }
+                }
+            }
+        }
+        (void)decoded;
+        counts[st]++;
+        if (out_msgs) out_msgs[i] = o;
+        if (out_status) out_status[i] = (uint8_t)st;
+    }
+}
+
 /*
  * raft.go:1231-1243 — MsgCheckQuorum over G groups: out = QuorumActive(), then
  * every Progress except the leader's own (self bit) gets RecentActive = false.

@@ -6,6 +6,7 @@ load time (there is deliberately no fallback).
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -38,7 +39,14 @@ SYMBOLS = [
     "rafthip_heartbeat_commit", "rafthip_upload_self", "rafthip_check_quorum",
     "rafthip_read_active", "rafthip_read_acks", "rafthip_read_term_range",
     "rafthip_committed_in_term", "rafthip_read_committed_in_term",
+    "rafthip_upload_ids", "rafthip_upload_term", "rafthip_upload_read_ctx", "rafthip_ingest_wire",
 ]
+
+
+WIRE_STATUSES = 8
+(WIRE_APPLIED, WIRE_OTHER_TYPE, WIRE_NO_PROGRESS, WIRE_STALE_TERM, WIRE_HIGHER_TERM, WIRE_NESTED, WIRE_MALFORMED,
+ WIRE_BAD_GROUP) = range(8)
+MSGF_READ_CTX, MSGF_HAS_CTX = 1, 2
 
 
 class RafthipError(RuntimeError):
@@ -63,6 +71,26 @@ def library_path():
     return os.environ.get("RAFTHIP_LIBRARY", os.path.join(_HERE, "lib", "librafthip.so"))
 
 
+def _share_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm ships its own libamdhip64.so.7; if this library
+    pulls in /opt/rocm's copy first and torch is imported later, the process holds two runtimes and
+    the second one finds no GPU ("No HIP GPUs are available").  When torch is installed but not yet
+    imported, load its runtime first so that librafthip.so binds to the same one either way
+    (RAFTHIP_SYSTEM_HIP=1 keeps the system runtime: for processes that never import torch)."""
+    if "torch" in sys.modules or os.environ.get("RAFTHIP_SYSTEM_HIP") == "1":
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        for d in (spec.submodule_search_locations or []) if spec else []:
+            cand = os.path.join(d, "lib", "libamdhip64.so")
+            if os.path.exists(cand):
+                C.CDLL(cand, mode=C.RTLD_GLOBAL)
+                return
+    except (ImportError, OSError, ValueError):
+        pass
+
+
 def load_library():
     global _LIB
     if _LIB is not None:
@@ -71,6 +99,7 @@ def load_library():
     if not os.path.exists(path):
         raise RafthipError(-2, "%s not found: build it with `python -c 'import __graft_entry__ as g; "
                            "g.build()'` (hipcc --offload-arch=gfx950); there is no CPU fallback" % path)
+    _share_torch_hip_runtime()
     L = C.CDLL(path)
     vp, u64, u32, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int
     sig = {
@@ -116,6 +145,10 @@ def load_library():
         "rafthip_read_term_range": (i32, [vp, u64, u64, vp, vp]),
         "rafthip_committed_in_term": (i32, [vp]),
         "rafthip_read_committed_in_term": (i32, [vp, u64, u64, vp]),
+        "rafthip_upload_ids": (i32, [vp, u64, u64, vp, u64]),
+        "rafthip_upload_term": (i32, [vp, u64, u64, vp]),
+        "rafthip_upload_read_ctx": (i32, [vp, u64, u64, vp, vp]),
+        "rafthip_ingest_wire": (i32, [vp, vp, vp, vp, u64, vp, vp, vp]),
     }
     assert sorted(sig) == sorted(SYMBOLS)
     for name, (res, args) in sig.items():
@@ -281,6 +314,32 @@ class Engine:
         if n is None:
             n = len(msgs)
         _check(self._L.rafthip_ingest_msgs(self._h, _ptr(msgs), n))
+
+    def upload_ids(self, ids, first=0, count=None):
+        """ids [S][count] uint64: the raft id behind each Progress row, 0 = empty."""
+        first, count = self._range(first, count)
+        assert ids.dtype == np.uint64 and ids.shape == (self.S, count) and ids.flags["C_CONTIGUOUS"]
+        _check(self._L.rafthip_upload_ids(self._h, first, count, _ptr(ids), count))
+
+    def upload_term(self, term, first=0, count=None):
+        first, count = self._range(first, count)
+        _check(self._L.rafthip_upload_term(self._h, first, count, _ptr(term)))
+
+    def upload_read_ctx(self, ctx, ctx_len, first=0, count=None):
+        first, count = self._range(first, count)
+        _check(self._L.rafthip_upload_read_ctx(self._h, first, count, _ptr(ctx), _ptr(ctx_len)))
+
+    def ingest_wire(self, data, offsets, groups, n=None, want_msgs=True, want_status=True, want_counts=True):
+        """Serialized raftpb.Message values -> (out_msgs, out_status, counts[8]); data / offsets / groups
+        are numpy arrays or raw device pointers (then pass n)."""
+        if n is None:
+            n = len(groups)
+        msgs = np.zeros(n, dtype=MSG_DTYPE) if want_msgs else None
+        status = np.zeros(n, dtype=np.uint8) if want_status else None
+        counts = np.zeros(WIRE_STATUSES, dtype=np.uint64) if want_counts else None
+        _check(self._L.rafthip_ingest_wire(self._h, _ptr(data), _ptr(offsets), _ptr(groups), n, _ptr(msgs),
+                                           _ptr(status), _ptr(counts)))
+        return msgs, status, counts
 
     def heartbeat_commit(self, first=0, count=None, download=True):
         first, count = self._range(first, count)

@@ -9,6 +9,7 @@
 #include <new>
 
 #include "kernels.h"
+#include "wire.h"
 #include "rafthip.h"
 
 using namespace rafthip;
@@ -16,6 +17,13 @@ using namespace rafthip;
 static_assert(sizeof(Pair) == sizeof(rafthip_commit_pair), "pair layout");
 static_assert(sizeof(Ack) == sizeof(rafthip_ack), "ack layout");
 static_assert(sizeof(Msg) == sizeof(rafthip_msg) && sizeof(Msg) == 16, "msg layout");
+static_assert(kWireApplied == RAFTHIP_WIRE_APPLIED && kWireOtherType == RAFTHIP_WIRE_OTHER_TYPE &&
+                  kWireNoProgress == RAFTHIP_WIRE_NO_PROGRESS && kWireStaleTerm == RAFTHIP_WIRE_STALE_TERM &&
+                  kWireHigherTerm == RAFTHIP_WIRE_HIGHER_TERM && kWireNested == RAFTHIP_WIRE_NESTED &&
+                  kWireMalformed == RAFTHIP_WIRE_MALFORMED && kWireBadGroup == RAFTHIP_WIRE_BAD_GROUP &&
+                  kWireStatuses == RAFTHIP_WIRE_STATUSES && kMsgFlagHasCtx == RAFTHIP_MSGF_HAS_CTX &&
+                  kWireNoSlot == RAFTHIP_WIRE_NO_SLOT,
+              "wire constants");
 static_assert(kMsgAppResp == RAFTHIP_MSG_APP_RESP && kMsgHeartbeatResp == RAFTHIP_MSG_HEARTBEAT_RESP &&
                   kMsgAppended == RAFTHIP_MSG_APPENDED && kMsgFlagCtx == RAFTHIP_MSGF_READ_CTX,
               "msg constants");
@@ -97,6 +105,15 @@ struct rafthip_engine {
     u64 ack_cap = 0;
     u64* d_rejected = nullptr;  // [0] acks without Progress, [1] msgs without Progress, [2] msgs of other types
     u64* h_scalar = nullptr;    // pinned, 4 x u64
+
+    // wire ingest
+    u64* ids = nullptr;            // [G][S] raft id per Progress row, 0 = empty
+    u64* cur_term = nullptr;       // r.Term per group
+    u64* read_ctx = nullptr;       // pending ReadIndex context (<= 8 bytes, little-endian) ...
+    uint8_t* read_ctx_len = nullptr;  // ... and its length, 0 = none
+    u64* d_wire_counts = nullptr;  // [RAFTHIP_WIRE_STATUSES]
+    void* wire_buf[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // staging: bytes, offsets, groups, out msgs, out status
+    size_t wire_cap[5] = {0, 0, 0, 0, 0};
 
     rafthip_stats_t stats{};
 };
@@ -446,6 +463,41 @@ static int commit_report(rafthip_engine* e, rafthip_commit_pair* dst, uint64_t m
     return RAFTHIP_OK;
 }
 
+bool is_device_ptr(const void* p) {
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, p) == hipSuccess && attr.type == hipMemoryTypeDevice) return true;
+    (void)hipGetLastError();  // plain host memory reports an error on some runtimes
+    return false;
+}
+
+// Growable device staging buffer k of the wire path.
+int wire_reserve(rafthip_engine* e, int k, size_t bytes) {
+    if (e->wire_cap[k] >= bytes) return RAFTHIP_OK;
+    if (e->wire_buf[k]) {
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        HIP_TRY(hipFree(e->wire_buf[k]));
+        e->wire_buf[k] = nullptr;
+        e->wire_cap[k] = 0;
+    }
+    HIP_TRY(hipMalloc(&e->wire_buf[k], bytes));
+    e->wire_cap[k] = bytes;
+    return RAFTHIP_OK;
+}
+
+// Input k of the wire path as a device pointer (host memory is copied in).
+int wire_input(rafthip_engine* e, int k, const void* src, size_t bytes, const void** dev) {
+    if (bytes == 0 || is_device_ptr(src)) {
+        *dev = src;
+        return RAFTHIP_OK;
+    }
+    int rc = wire_reserve(e, k, bytes);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(e->wire_buf[k], src, bytes, hipMemcpyHostToDevice, e->stream));
+    e->stats.bytes_uploaded += bytes;
+    *dev = e->wire_buf[k];
+    return RAFTHIP_OK;
+}
+
 }  // namespace
 
 // ==========================================================================
@@ -544,7 +596,9 @@ int rafthip_destroy(rafthip_engine* e) {
     void* bufs[] = {e->in_mask, e->out_mask,   e->learner_mask, e->match,    e->commit, e->votes,
                     e->active,  e->acks,       e->vote_result,  e->granted,  e->rejected, e->qactive,
                     e->ack_result, e->stage,   e->packed,       e->counts,   e->offsets,  e->ack_buf,
-                    e->d_rejected, e->self_mask, e->term_first, e->term_last, e->hb_commit, e->in_term};
+                    e->d_rejected, e->self_mask, e->term_first, e->term_last, e->hb_commit, e->in_term,
+                    e->ids, e->cur_term, e->read_ctx, e->read_ctx_len, e->d_wire_counts,
+                    e->wire_buf[0], e->wire_buf[1], e->wire_buf[2], e->wire_buf[3], e->wire_buf[4]};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (e->h_scalar) (void)hipHostFree(e->h_scalar);
@@ -773,6 +827,145 @@ int rafthip_ingest_msgs(rafthip_engine* e, const rafthip_msg* msgs, uint64_t n) 
         HIP_TRY(hipGetLastError());
     }
     if (staged) HIP_TRY(hipStreamSynchronize(e->stream));
+    e->stats.msgs_ingested += n;
+    return RAFTHIP_OK;
+}
+
+// ---- wire ingest -----------------------------------------------------------
+
+int rafthip_upload_ids(rafthip_engine* e, uint64_t first, uint64_t count, const uint64_t* ids,
+                       uint64_t src_stride) {
+    int rc = check_range(e, first, count);
+    if (rc) return rc;
+    if (!ids) return fail(RAFTHIP_EINVAL, "ids is NULL");
+    if (src_stride < count) return fail(RAFTHIP_EINVAL, "src_stride %llu < count %llu", (u64)src_stride, (u64)count);
+    DeviceGuard guard(e->device);
+    if ((rc = ensure(e, e->ids, (size_t)e->G * e->S * sizeof(u64)))) return rc;
+    if (count == 0) return RAFTHIP_OK;
+    void* tmp = nullptr;
+    HIP_TRY(hipMalloc(&tmp, (size_t)count * e->S * sizeof(u64)));
+    hipError_t err = hipMemcpy2DAsync(tmp, count * 8, ids, src_stride * 8, count * 8, e->S, hipMemcpyDefault, e->stream);
+    if (err == hipSuccess) {
+        hipLaunchKernelGGL(k_ids_to_rows, dim3((u32)((count + kBlock - 1) / kBlock)), dim3(kBlock), 0, e->stream,
+                           static_cast<const u64*>(tmp), (u64)count, e->S, e->ids + first * e->S);
+        err = hipGetLastError();
+    }
+    const hipError_t err2 = hipStreamSynchronize(e->stream);
+    (void)hipFree(tmp);
+    HIP_TRY(err);
+    HIP_TRY(err2);
+    e->stats.bytes_uploaded += count * 8 * e->S;
+    return RAFTHIP_OK;
+}
+
+int rafthip_upload_term(rafthip_engine* e, uint64_t first, uint64_t count, const uint64_t* term) {
+    int rc = check_range(e, first, count);
+    if (rc) return rc;
+    if (!term) return fail(RAFTHIP_EINVAL, "term is NULL");
+    DeviceGuard guard(e->device);
+    if ((rc = ensure(e, e->cur_term, (size_t)e->stride * sizeof(u64)))) return rc;
+    HIP_TRY(hipMemcpyAsync(e->cur_term + first, term, count * 8, hipMemcpyDefault, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    e->stats.bytes_uploaded += count * 8;
+    return RAFTHIP_OK;
+}
+
+int rafthip_upload_read_ctx(rafthip_engine* e, uint64_t first, uint64_t count, const uint64_t* ctx,
+                            const uint8_t* ctx_len) {
+    int rc = check_range(e, first, count);
+    if (rc) return rc;
+    if (!ctx || !ctx_len) return fail(RAFTHIP_EINVAL, "ctx/ctx_len is NULL");
+    DeviceGuard guard(e->device);
+    if ((rc = ensure(e, e->read_ctx, (size_t)e->stride * sizeof(u64)))) return rc;
+    if ((rc = ensure(e, e->read_ctx_len, (size_t)e->stride))) return rc;
+    HIP_TRY(hipMemcpyAsync(e->read_ctx + first, ctx, count * 8, hipMemcpyDefault, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->read_ctx_len + first, ctx_len, count, hipMemcpyDefault, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    e->stats.bytes_uploaded += count * 9;
+    return RAFTHIP_OK;
+}
+
+int rafthip_ingest_wire(rafthip_engine* e, const uint8_t* bytes, const uint64_t* offsets, const uint32_t* groups,
+                        uint64_t n, rafthip_msg* out_msgs, uint8_t* out_status, uint64_t* status_counts) {
+    if (!e) return fail(RAFTHIP_EINVAL, "engine is NULL");
+    if (status_counts) memset(status_counts, 0, RAFTHIP_WIRE_STATUSES * sizeof(uint64_t));
+    if (n == 0) return RAFTHIP_OK;
+    if (!offsets || !groups) return fail(RAFTHIP_EINVAL, "offsets/groups is NULL");
+    if (!e->ids || !e->cur_term)
+        return fail(RAFTHIP_EINVAL, "rafthip_upload_ids and rafthip_upload_term must come first");
+    DeviceGuard guard(e->device);
+    int rc;
+    const size_t mb = (size_t)e->stride * e->mbytes;
+    if ((rc = ensure(e, e->active, mb))) return rc;
+    if ((rc = ensure(e, e->acks, mb))) return rc;
+    if ((rc = ensure(e, e->read_ctx, (size_t)e->stride * sizeof(u64)))) return rc;
+    if ((rc = ensure(e, e->read_ctx_len, (size_t)e->stride))) return rc;
+    if ((rc = ensure(e, e->d_wire_counts, RAFTHIP_WIRE_STATUSES * sizeof(u64)))) return rc;
+
+    // total byte length = offsets[n] (the kernel bounds every message by it)
+    const void* d_off = nullptr;
+    u64 nbytes = 0;
+    if (is_device_ptr(offsets)) {
+        HIP_TRY(hipMemcpyAsync(e->h_scalar + 2, offsets + n, sizeof(u64), hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        nbytes = e->h_scalar[2];
+        d_off = offsets;
+    } else {
+        nbytes = offsets[n];
+        if ((rc = wire_input(e, 1, offsets, (size_t)(n + 1) * sizeof(u64), &d_off))) return rc;
+    }
+    if (nbytes > 0 && !bytes) return fail(RAFTHIP_EINVAL, "bytes is NULL");
+    const void *d_bytes = nullptr, *d_groups = nullptr;
+    if ((rc = wire_input(e, 0, bytes, (size_t)nbytes, &d_bytes))) return rc;
+    if ((rc = wire_input(e, 2, groups, (size_t)n * sizeof(u32), &d_groups))) return rc;
+    Msg* d_msgs = nullptr;
+    uint8_t* d_status = nullptr;
+    const bool msgs_host = out_msgs && !is_device_ptr(out_msgs);
+    const bool status_host = out_status && !is_device_ptr(out_status);
+    if (out_msgs) {
+        if (msgs_host) {
+            if ((rc = wire_reserve(e, 3, (size_t)n * sizeof(Msg)))) return rc;
+            d_msgs = static_cast<Msg*>(e->wire_buf[3]);
+        } else {
+            d_msgs = reinterpret_cast<Msg*>(out_msgs);
+        }
+    }
+    if (out_status) {
+        if (status_host) {
+            if ((rc = wire_reserve(e, 4, (size_t)n))) return rc;
+            d_status = static_cast<uint8_t*>(e->wire_buf[4]);
+        } else {
+            d_status = out_status;
+        }
+    }
+    HIP_TRY(hipMemsetAsync(e->d_wire_counts, 0, RAFTHIP_WIRE_STATUSES * sizeof(u64), e->stream));
+    for (u64 off = 0; off < n; off += kMaxRecordsPerLaunch) {
+        const u64 m = n - off < kMaxRecordsPerLaunch ? n - off : kMaxRecordsPerLaunch;
+        const u32 blocks = (u32)((m + kWireBlock - 1) / kWireBlock);
+        hipLaunchKernelGGL(k_ingest_wire, dim3(blocks), dim3(kWireBlock), 0, e->stream,
+                           static_cast<const uint8_t*>(d_bytes), nbytes, static_cast<const u64*>(d_off) + off,
+                           static_cast<const u32*>(d_groups) + off, m, e->G, e->S, e->ids, e->cur_term, e->read_ctx,
+                           e->read_ctx_len, e->match, e->stride, e->active, e->acks, e->mbytes,
+                           d_msgs ? d_msgs + off : nullptr, d_status ? d_status + off : nullptr, e->d_wire_counts);
+        HIP_TRY(hipGetLastError());
+    }
+    bool wait = d_bytes != bytes || d_off != offsets || d_groups != groups;  // caller may reuse its host buffers
+    if (msgs_host) {
+        HIP_TRY(hipMemcpyAsync(out_msgs, d_msgs, (size_t)n * sizeof(Msg), hipMemcpyDeviceToHost, e->stream));
+        e->stats.bytes_downloaded += n * sizeof(Msg);
+        wait = true;
+    }
+    if (status_host) {
+        HIP_TRY(hipMemcpyAsync(out_status, d_status, (size_t)n, hipMemcpyDeviceToHost, e->stream));
+        e->stats.bytes_downloaded += n;
+        wait = true;
+    }
+    if (status_counts) {
+        HIP_TRY(hipMemcpyAsync(status_counts, e->d_wire_counts, RAFTHIP_WIRE_STATUSES * sizeof(u64),
+                               hipMemcpyDeviceToHost, e->stream));
+        wait = true;
+    }
+    if (wait) HIP_TRY(hipStreamSynchronize(e->stream));
     e->stats.msgs_ingested += n;
     return RAFTHIP_OK;
 }

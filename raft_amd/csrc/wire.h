@@ -1,0 +1,283 @@
+// wire.h — K8: raftpb.Message bytes -> stepLeader bookkeeping, on the device.
+//
+// One lane decodes one gogo-protobuf serialized raftpb.Message
+// (raftpb/raft.proto:71-108) the way Message.Unmarshal does
+// (raftpb/raft.pb.go:1801-2179, skipRaft :3027-3104), applies raft.Step's term
+// gate (raft.go:1051-1139), looks the sender up in the group's id table
+// (`r.trk.Progress[m.From]`, raft.go:1327) and performs the same max / or
+// updates as K7.  A workgroup's messages are one contiguous byte range: it is
+// staged into LDS with 16-byte loads and parsed from there; a range that does
+// not fit is parsed straight from global memory.
+#pragma once
+#include "kernels.h"
+
+namespace rafthip {
+
+using i64 = long long;
+
+constexpr int kWireBlock = 256;         // messages per workgroup
+constexpr u32 kWireLdsBytes = 24576;    // staged bytes per workgroup (96 B per message on average)
+
+enum : uint8_t {  // = RAFTHIP_WIRE_*
+    kWireApplied = 0,
+    kWireOtherType = 1,
+    kWireNoProgress = 2,
+    kWireStaleTerm = 3,
+    kWireHigherTerm = 4,
+    kWireNested = 5,
+    kWireMalformed = 6,
+    kWireBadGroup = 7,
+    kWireStatuses = 8,
+};
+constexpr uint8_t kMsgFlagHasCtx = 2;
+constexpr uint8_t kWireNoSlot = 0xFF;
+
+struct WireFields {
+    u32 type;      // int32 MessageType: the low 32 bits of the varint
+    u64 from, term, index;
+    bool reject;
+    bool nested;   // a non-empty entries / snapshot / responses payload was seen
+    u64 ctx;       // first min(ctx_len, 8) bytes of Context, little-endian
+    u64 ctx_len;
+};
+
+struct GlobalBytes {
+    const uint8_t* p;
+    __device__ __forceinline__ u32 operator()(i64 pos) const { return p[pos]; }
+};
+struct LdsBytes {
+    const uint8_t* sm;  // sm[0] holds byte `base`
+    i64 base;
+    __device__ __forceinline__ u32 operator()(i64 pos) const { return sm[pos - base]; }
+};
+
+// The varint loop every field of Unmarshal uses (e.g. raft.pb.go:1807-1820):
+// at most 10 bytes, bits past 63 are shifted out, running off the buffer or an
+// 11th byte is an error.
+template <class R>
+__device__ __forceinline__ bool wire_varint(const R& rd, i64& pos, i64 end, u64& v) {
+    v = 0;
+    for (u32 shift = 0;; shift += 7) {
+        if (shift >= 64) return false;  // ErrIntOverflowRaft
+        if (pos >= end) return false;   // io.ErrUnexpectedEOF
+        const u32 b = rd(pos++);
+        v |= (u64)(b & 0x7Fu) << shift;
+        if (b < 0x80u) return true;
+    }
+}
+
+// skipRaft (raft.pb.go:3027-3104) on [pos, end): skips one unknown field,
+// groups included.  The caller's `iNdEx + skippy > l` check is folded in.
+template <class R>
+__device__ bool wire_skip(const R& rd, i64& pos, i64 end) {
+    i64 i = pos;
+    int depth = 0;
+    while (i < end) {
+        u64 wire;
+        if (!wire_varint(rd, i, end, wire)) return false;
+        switch ((u32)wire & 7u) {
+            case 0: {
+                u64 ignored;
+                if (!wire_varint(rd, i, end, ignored)) return false;
+                break;
+            }
+            case 1: i += 8; break;
+            case 2: {
+                u64 len;
+                if (!wire_varint(rd, i, end, len)) return false;
+                if ((i64)len < 0 || (i64)len > end - i) return false;  // ErrInvalidLengthRaft / past the end
+                i += (i64)len;
+                break;
+            }
+            case 3: ++depth; break;
+            case 4:
+                if (depth == 0) return false;  // ErrUnexpectedEndOfGroupRaft
+                --depth;
+                break;
+            case 5: i += 4; break;
+            default: return false;  // illegal wireType 6, 7
+        }
+        if (i > end) return false;
+        if (depth == 0) {
+            pos = i;
+            return true;
+        }
+    }
+    return false;  // io.ErrUnexpectedEOF inside a group
+}
+
+// Message.Unmarshal's top level.  Returns false where the reference returns an
+// error.  Nested messages (fields 7, 9, 14) are measured, not decoded: a
+// non-empty one sets `nested` and the message is left to the host.
+template <class R>
+__device__ bool wire_parse(const R& rd, i64 pos, i64 end, WireFields& f) {
+    f.type = 0;
+    f.from = f.term = f.index = 0;
+    f.reject = f.nested = false;
+    f.ctx = f.ctx_len = 0;
+    while (pos < end) {
+        const i64 pre = pos;
+        u64 wire;
+        if (!wire_varint(rd, pos, end, wire)) return false;
+        const int32_t field = (int32_t)(u32)(wire >> 3);  // fieldNum := int32(wire >> 3)
+        const u32 wt = (u32)wire & 7u;
+        if (wt == 4) return false;     // end group for non-group
+        if (field <= 0) return false;  // illegal tag
+        switch (field) {
+            case 1: case 2: case 3: case 4: case 5: case 6: case 8: case 10: case 11: case 13: {
+                if (wt != 0) return false;  // wrong wireType
+                u64 v;
+                if (!wire_varint(rd, pos, end, v)) return false;
+                if (field == 1) f.type = (u32)v;
+                else if (field == 3) f.from = v;
+                else if (field == 4) f.term = v;
+                else if (field == 6) f.index = v;
+                else if (field == 10) f.reject = v != 0;
+                break;
+            }
+            case 7: case 9: case 12: case 14: {
+                if (wt != 2) return false;
+                u64 len;
+                if (!wire_varint(rd, pos, end, len)) return false;
+                if ((i64)len < 0) return false;           // ErrInvalidLengthRaft
+                if ((i64)len > end - pos) return false;   // io.ErrUnexpectedEOF
+                if (field == 12) {                        // last occurrence wins (:2101)
+                    f.ctx_len = len;
+                    f.ctx = 0;
+                    const u32 k = len < 8 ? (u32)len : 8u;
+                    for (u32 j = 0; j < k; ++j) f.ctx |= (u64)rd(pos + j) << (8 * j);
+                } else if (len > 0) {
+                    f.nested = true;
+                }
+                pos += (i64)len;
+                break;
+            }
+            default:
+                pos = pre;
+                if (!wire_skip(rd, pos, end)) return false;
+        }
+    }
+    return true;
+}
+
+__global__ __launch_bounds__(kWireBlock) void k_ingest_wire(
+    const uint8_t* __restrict__ bytes, u64 nbytes, const u64* __restrict__ offsets,
+    const u32* __restrict__ groups, u64 n, u64 G, u32 S, const u64* __restrict__ ids /* [G][S] */,
+    const u64* __restrict__ cur_term, const u64* __restrict__ read_ctx,
+    const uint8_t* __restrict__ read_ctx_len, u64* __restrict__ match, u64 stride,
+    void* __restrict__ active, void* __restrict__ acks, int mbytes, Msg* __restrict__ out_msgs,
+    uint8_t* __restrict__ out_status, u64* __restrict__ counters /* [kWireStatuses] */) {
+    __shared__ __align__(16) uint8_t sm[kWireLdsBytes + 32];
+    __shared__ u32 hist[kWireStatuses];
+    const u64 i0 = (u64)blockIdx.x * kWireBlock;
+    const u64 cnt = n - i0 < (u64)kWireBlock ? n - i0 : (u64)kWireBlock;
+    if (threadIdx.x < kWireStatuses) hist[threadIdx.x] = 0;
+
+    // the workgroup's byte window [w0, w1)
+    const u64 w0 = offsets[i0], w1 = offsets[i0 + cnt];
+    const bool window = w0 <= w1 && w1 <= nbytes && w1 - w0 <= kWireLdsBytes;
+    u32 lead = 0;  // sm[lead] holds byte w0
+    if (window && w1 > w0) {
+        const uintptr_t a0 = reinterpret_cast<uintptr_t>(bytes + w0);
+        const uintptr_t a1 = reinterpret_cast<uintptr_t>(bytes + w1);
+        const uintptr_t base = a0 & ~(uintptr_t)15;
+        lead = (u32)(a0 - base);
+        const uintptr_t full = a1 & ~(uintptr_t)15;  // 16-byte granules wholly below a1
+        for (uintptr_t a = base + (uintptr_t)threadIdx.x * 16; a < full; a += (uintptr_t)kWireBlock * 16) {
+            // the first granule may start below bytes + w0: same 16-byte granule as a valid byte
+            *reinterpret_cast<uint4*>(sm + (a - base)) = *reinterpret_cast<const uint4*>(a);
+        }
+        if (full >= base) {  // tail bytes of the last, partial granule
+            const uintptr_t t0 = full > a0 ? full : a0;
+            for (uintptr_t a = t0 + threadIdx.x; a < a1; a += kWireBlock)
+                sm[a - base] = *reinterpret_cast<const uint8_t*>(a);
+        }
+    }
+    __syncthreads();
+
+    const u64 i = i0 + threadIdx.x;
+    if (i < n) {
+        const u64 start = offsets[i], end = offsets[i + 1];
+        const u32 group = groups[i];
+        uint8_t status = kWireApplied;
+        WireFields f;
+        bool decoded = false;
+        if ((u64)group >= G) {
+            status = kWireBadGroup;
+        } else if (!(start <= end && end <= nbytes)) {
+            status = kWireMalformed;
+        } else {
+            if (window && start >= w0 && end <= w1) {
+                decoded = wire_parse(LdsBytes{sm + lead, (i64)w0}, (i64)start, (i64)end, f);
+            } else {
+                decoded = wire_parse(GlobalBytes{bytes}, (i64)start, (i64)end, f);
+            }
+            if (!decoded) status = kWireMalformed;
+        }
+        u32 slot = kWireNoSlot;
+        uint8_t flags = 0;
+        if (decoded) {
+            if (f.ctx_len > 0) flags |= kMsgFlagHasCtx;
+            const bool app = f.type == kMsgAppResp, hb = f.type == kMsgHeartbeatResp;
+            if (!app && !hb) {
+                status = kWireOtherType;
+            } else if (f.nested) {
+                status = kWireNested;
+            } else {
+                const u64 term = cur_term[group];
+                if (f.term != 0 && f.term > term) {
+                    status = kWireHigherTerm;
+                } else if (f.term != 0 && f.term < term) {
+                    status = kWireStaleTerm;
+                } else {
+                    const u64* row = ids + (u64)group * S;
+                    if (f.from != 0) {
+                        for (u32 s = 0; s < S; ++s) {
+                            if (row[s] == f.from) {
+                                slot = s;
+                                break;
+                            }
+                        }
+                    }
+                    if (slot == kWireNoSlot) {
+                        status = kWireNoProgress;
+                    } else {
+                        or_slot_bit(active, mbytes, group, slot);  // raft.go:1337,1528
+                        if (app) {
+                            if (!f.reject) atomicMax(match + (u64)slot * stride + group, f.index);  // :1477
+                        } else {
+                            const u32 want = read_ctx_len[group];
+                            if (want != 0 && f.ctx_len == want && f.ctx == read_ctx[group]) {
+                                flags |= kMsgFlagCtx;
+                                or_slot_bit(acks, mbytes, group, slot);  // read_only.go:68-76
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        if (out_msgs) {
+            Vec<u64, 2> o;
+            const u32 type8 = decoded ? (f.type <= 0xFFu ? f.type : 0xFFu) : 0xFFu;
+            o.v[0] = (u64)group | ((u64)(slot & 0xFFu) << 32) | ((u64)type8 << 40) |
+                     ((u64)(decoded && f.reject ? 1 : 0) << 48) | ((u64)flags << 56);
+            o.v[1] = decoded ? f.index : 0;
+            store_vec<u64, 2>(reinterpret_cast<u64*>(out_msgs + i), o);
+        }
+        if (out_status) out_status[i] = status;
+        atomicAdd(&hist[status], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < kWireStatuses && hist[threadIdx.x] != 0) atomicAdd(counters + threadIdx.x, (u64)hist[threadIdx.x]);
+}
+
+// Id table upload: [S][count] planes (the layout every other upload uses) ->
+// group-major rows, so one lookup reads one contiguous run of S ids.
+__global__ __launch_bounds__(kBlock) void k_ids_to_rows(const u64* __restrict__ src, u64 count, u32 S,
+                                                        u64* __restrict__ dst) {
+    const u64 g = (u64)blockIdx.x * kBlock + threadIdx.x;
+    if (g >= count) return;
+    for (u32 s = 0; s < S; ++s) dst[g * S + s] = src[(u64)s * count + g];
+}
+
+}  // namespace rafthip

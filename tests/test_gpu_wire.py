@@ -1,0 +1,170 @@
+"""GPU parity for the serialized-message ingest:
+rafthip_ingest_wire decodes gogo-protobuf raftpb.Message bytes on the device
+(raftpb/raft.pb.go:1801-2179, skipRaft :3027-3104), applies raft.Step's term
+gate (raft.go:1051-1139) and the Progress lookup of raft.go:1327, then the
+stepLeader bookkeeping.  Bit-exact vs the oracle stepping the same bytes one
+message at a time; through the C ABI."""
+import numpy as np
+import pytest
+
+import golden_util as gu
+import raft_amd
+import wire_util as wu
+from raft_amd import capi
+from test_wire_cpu import HAND, OK, make_state
+
+pytestmark = pytest.mark.gpu
+
+
+def run_both(oracle, e, state, data, offsets, groups, device_inputs=False):
+    ids, term, ctxs, match, active, acks = state
+    cw, cl = wu.ctx_words(ctxs)
+    wm, wa, wk = match.copy(), active.copy(), acks.copy()
+    want_msgs, want_status, want_counts = oracle.step_wire_msgs(wm, wa, wk, ids, term, cw, cl, data, offsets, groups)
+    e.upload_match(match)
+    e.upload_active(active)
+    e.upload_acks(acks)
+    e.upload_ids(ids)
+    e.upload_term(term)
+    e.upload_read_ctx(cw, cl)
+    if device_inputs:
+        import torch
+        keep = [torch.from_numpy(data.copy()).cuda() if len(data) else torch.zeros(1, dtype=torch.uint8, device="cuda"),
+                torch.from_numpy(offsets.view(np.int64).copy()).cuda(),
+                torch.from_numpy(groups.view(np.int32).copy()).cuda()]
+        msgs, status, counts = e.ingest_wire(keep[0], keep[1], keep[2], n=len(groups))
+    else:
+        msgs, status, counts = e.ingest_wire(data, offsets, groups)
+    assert np.array_equal(status, want_status)
+    assert np.array_equal(counts, want_counts)
+    assert np.array_equal(msgs, want_msgs)
+    assert np.array_equal(e.read_match(), wm)
+    assert np.array_equal(e.read_active(), wa)
+    assert np.array_equal(e.read_acks(), wk)
+    return want_counts
+
+
+@pytest.mark.parametrize("S,device_inputs", [(3, False), (5, True), (9, False), (16, True), (33, False), (64, False)])
+def test_ingest_wire_random_batches(oracle, S, device_inputs):
+    rng = np.random.default_rng(1200 + S)
+    G, n = 997, 30000
+    state = make_state(rng, S, G)
+    msgs, groups = wu.random_batch(rng, n, G, state[0], state[1], state[2])
+    data, offsets = wu.pack(msgs)
+    with raft_amd.Engine(G, S) as e:
+        counts = run_both(oracle, e, state, data, offsets, groups, device_inputs)
+        assert counts.sum() == n and (counts > 0).all()
+        assert e.stats()["msgs_ingested"] == n
+
+
+def test_ingest_wire_hand_vectors(oracle):
+    """The hand-derived Unmarshal vectors of tests/test_wire_cpu.py, each as its own message
+    and all in one batch: malformed ones are status 6, the rest decode to the stated fields."""
+    S, G = 3, 2
+    ids = np.array([[1, 5], [2, 6], [3, 7]], dtype=np.uint64)
+    term = np.array([2, 2], dtype=np.uint64)
+    state = (ids, term, [b"ab", b""], np.zeros((S, G), dtype=np.uint64), np.zeros(G, dtype=np.uint8),
+             np.zeros(G, dtype=np.uint8))
+    blobs = [b for b, _, _ in HAND]
+    data, offsets = wu.pack(blobs)
+    groups = np.zeros(len(blobs), dtype=np.uint32)
+    with raft_amd.Engine(G, S) as e:
+        run_both(oracle, e, state, data, offsets, groups)
+        _, status, _ = e.ingest_wire(data, offsets, groups)
+        for (b, rc, fields), st in zip(HAND, status):
+            assert (st == capi.WIRE_MALFORMED) == (rc != OK), (b, rc, st)
+        # one message per call: the byte window starts at arbitrary alignments
+        for k, (b, rc, fields) in enumerate(HAND):
+            msgs, status, _ = e.ingest_wire(data, offsets[k:k + 2], groups[:1])
+            assert (status[0] == capi.WIRE_MALFORMED) == (rc != OK)
+            if rc == OK and "index" in fields:
+                assert int(msgs["index"][0]) == fields["index"]
+
+
+def test_ingest_wire_long_messages_leave_the_lds_window(oracle):
+    """A workgroup whose 256 messages exceed the staged window parses from global memory:
+    long unknown fields and long contexts between ordinary responses."""
+    rng = np.random.default_rng(1300)
+    S, G, n = 5, 64, 3000
+    state = make_state(rng, S, G)
+    ids, term, ctxs = state[0], state[1], state[2]
+    msgs, groups = wu.random_batch(rng, n, G, ids, term, ctxs, bad_frac=0.05)
+    for i in range(0, n, 7):  # ~430 messages of 300..5000 bytes
+        pad = bytes(rng.integers(0, 256, size=int(rng.integers(300, 5000)), dtype=np.uint8))
+        if i % 2:
+            msgs[i] = wu.tag(99, 2) + wu.varint(len(pad)) + pad + msgs[i]
+        else:
+            msgs[i] = msgs[i] + wu.tag(12, 2) + wu.varint(len(pad)) + pad  # a later, longer context wins
+    data, offsets = wu.pack(msgs)
+    assert int(offsets[256]) > 24576
+    with raft_amd.Engine(G, S) as e:
+        counts = run_both(oracle, e, state, data, offsets, groups)
+        assert counts[capi.WIRE_APPLIED] > n // 2
+
+
+def test_ingest_wire_bad_offsets_and_empty(oracle):
+    rng = np.random.default_rng(1400)
+    S, G = 4, 8
+    state = make_state(rng, S, G)
+    ids, term = state[0], state[1]
+    g = 3
+    frm = int(ids[ids[:, g] != 0, g][0]) if (ids[:, g] != 0).any() else 1
+    b = wu.encode_message(type=wu.MSG_APP_RESP, frm=frm, term=int(term[g]), index=1 << 41)
+    data, _ = wu.pack([b, b, b, b])
+    L = len(b)
+    offsets = np.array([0, L, 9 * L, 3 * L, 4 * L], dtype=np.uint64)  # past the data, then backwards
+    groups = np.full(4, g, dtype=np.uint32)
+    with raft_amd.Engine(G, S) as e:
+        run_both(oracle, e, state, data, offsets, groups)
+        msgs, status, counts = e.ingest_wire(data, offsets, groups, n=0)
+        assert counts.sum() == 0
+        # empty messages (zero-length ranges) decode to the zero Message: type 0 = MsgHup, left to the host
+        z = np.zeros(5, dtype=np.uint64)
+        msgs, status, counts = e.ingest_wire(np.zeros(0, dtype=np.uint8), z, groups)
+        assert (status == capi.WIRE_OTHER_TYPE).all()
+
+
+def test_ingest_wire_requires_the_id_table():
+    with raft_amd.Engine(4, 3) as e:
+        with pytest.raises(raft_amd.RafthipError):
+            e.ingest_wire(np.zeros(1, dtype=np.uint8), np.array([0, 1], dtype=np.uint64), np.zeros(1, dtype=np.uint32))
+
+
+def test_ingest_wire_then_commit_full_size(oracle):
+    """cfg5 shape through the serialized path: 2^20 groups x (7 voters + 2 learners), 4M
+    serialized MsgAppResp / MsgHeartbeatResp, then the commit pass; every plane vs the oracle."""
+    G, S, V = 1 << 20, 9, 7
+    n = 4 * G
+    rng = np.random.default_rng(0x5EED0007)
+    ids = np.ascontiguousarray((np.arange(S, dtype=np.uint64)[:, None] + np.uint64(1)) * np.uint64(0x10001)
+                               + rng.integers(0, 1 << 16, size=G, dtype=np.uint64)[None, :] * np.uint64(1 << 20))
+    term = rng.integers(1, 1 << 20, size=G).astype(np.uint64)
+    match = (gu.dist_b(0x5EED0007, S, G) & np.uint64((1 << 40) - 1)) + np.uint64(64)
+    cw = rng.integers(1, 1 << 63, size=G, dtype=np.uint64)
+    cl = np.full(G, 8, dtype=np.uint8)
+    groups = rng.integers(0, G, size=n).astype(np.uint32)
+    slots = rng.integers(0, S, size=n)
+    data, offsets = wu.encode_responses(rng, ids[slots, groups], term[groups],
+                                        match[slots, groups] + rng.integers(0, 64, size=n).astype(np.uint64),
+                                        cw[groups])
+    active = np.ones(G, dtype=np.uint16)
+    acks = np.zeros(G, dtype=np.uint16)
+    wm, wa, wk = match.copy(), active.copy(), acks.copy()
+    _, want_status, want_counts = oracle.step_wire_msgs(wm, wa, wk, ids, term, cw, cl, data, offsets, groups)
+    with raft_amd.Engine(G, S) as e:
+        e.set_uniform_config(V)
+        e.upload_match(match)
+        e.upload_active(active)
+        e.upload_acks(acks)
+        e.upload_ids(ids)
+        e.upload_term(term)
+        e.upload_read_ctx(cw, cl)
+        _, status, counts = e.ingest_wire(data, offsets, groups, want_msgs=False)
+        assert np.array_equal(counts, want_counts) and np.array_equal(status, want_status)
+        assert counts[capi.WIRE_APPLIED] > 0.8 * n
+        e.commit()
+        assert np.array_equal(e.read_match(), wm)
+        assert np.array_equal(e.read_active(), wa)
+        assert np.array_equal(e.read_acks(), wk)
+        assert np.array_equal(e.read_commit(), oracle.batch_committed(wm, uniform_voters=V, threads=0))
+        assert (wm != match).any() and wk.any()
