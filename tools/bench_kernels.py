@@ -200,6 +200,29 @@ def main():
         timed("k_scatter_acks, random cells (K5)", "ack", N, 24, lambda: e.scatter_acks(d_recs.data_ptr(), N))
         timed("k_ingest_msgs, random cells (K7)", "msg", N, 24 + 4, lambda: e.ingest_msgs(d_msgs.data_ptr(), N))
         timed("k_commit_uniform<7> over 9 slots (K1)", "group", G, 64, e.commit)
+    # serialized responses (K8): same cells as the K7 stream, as gogo-protobuf bytes
+    if not args.only or args.only in "k_ingest_wire, random cells (K8)":
+        import wire_util as wu
+        ids = np.ascontiguousarray((np.arange(Sv, dtype=np.uint64)[:, None] + np.uint64(1)) * np.uint64(0x10001)
+                                   + rng.integers(0, 1 << 16, size=G, dtype=np.uint64)[None, :] * np.uint64(1 << 20))
+        term = rng.integers(1, 1 << 20, size=G).astype(np.uint64)
+        ctx = rng.integers(1, 1 << 63, size=G, dtype=np.uint64)
+        wm = m & np.uint64((1 << 40) - 1)
+        data, offsets = wu.encode_responses(rng, ids[recs["slot"], recs["group"]], term[recs["group"]],
+                                            wm[recs["slot"], recs["group"]] + np.uint64(17), ctx[recs["group"]])
+        d_data = torch.from_numpy(data).to(dev)
+        d_off = torch.from_numpy(offsets.view(np.int64)).to(dev)
+        d_grp = torch.from_numpy(recs["group"].astype(np.uint32).view(np.int32)).to(dev)
+        per_msg = len(data) / N + 12 + 8 * Sv + 8 + 8 + 4
+        with raft_amd.Engine(G, Sv, stream=stream.cuda_stream) as e:
+            e.set_uniform_config(7)
+            e.upload_match(wm)
+            e.upload_ids(ids)
+            e.upload_term(term)
+            e.upload_read_ctx(ctx, np.full(G, 8, dtype=np.uint8))
+            timed("k_ingest_wire, %.1f B messages, random cells (K8)" % (len(data) / N), "msg", N, round(per_msg),
+                  lambda: e.ingest_wire(d_data, d_off, d_grp, n=N, want_msgs=False, want_status=False, want_counts=False))
+        del data, offsets, d_data, d_off, d_grp
     # sorted-by-group stream (a host that buckets acks by range)
     order = np.argsort(recs["group"], kind="stable")
     d_recs = torch.from_numpy(np.ascontiguousarray(recs[order]).view(np.uint8)).to(dev)
