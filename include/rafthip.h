@@ -275,6 +275,87 @@ int rafthip_ingest_wire(rafthip_engine *e, const uint8_t *bytes, const uint64_t 
                         const uint32_t *groups, uint64_t n, rafthip_msg *out_msgs,
                         uint8_t *out_status, uint64_t *status_counts);
 
+/* ---- per-peer replication state: tracker.Progress + tracker.Inflights ------ */
+
+/* tracker.StateType, tracker/state.go:18-34. */
+#define RAFTHIP_STATE_PROBE 0
+#define RAFTHIP_STATE_REPLICATE 1
+#define RAFTHIP_STATE_SNAPSHOT 2
+#define RAFTHIP_PROGRESS_PAUSED 4 /* bit 2 of a state byte: Progress.MsgAppFlowPaused */
+
+/* Event types of rafthip_step_progress beyond MsgAppResp / MsgHeartbeatResp /
+ * RAFTHIP_MSG_APPENDED (raftpb/raft.proto:41-69 and two local send-side records). */
+#define RAFTHIP_MSG_UNREACHABLE 10 /* MsgUnreachable, raft.go:1580-1586 */
+#define RAFTHIP_MSG_SNAP_STATUS 11 /* MsgSnapStatus, raft.go:1562-1579; reject = the snapshot failed */
+#define RAFTHIP_MSG_SENT_APP 0xF1  /* a MsgApp went out: Progress.UpdateOnEntriesSend (raft.go:653,
+                                      tracker/progress.go:141-163); flags bit 0 = it carried entries,
+                                      index = index of its last entry, aux = payload bytes */
+#define RAFTHIP_MSG_SENT_SNAP 0xF2 /* a MsgSnap went out: Progress.BecomeSnapshot(index), raft.go:645 */
+
+/* What the reference does next with a stepped message — left to the host. */
+#define RAFTHIP_ACT_SEND_APPEND 1 /* r.sendAppend(m.From): raft.go:1465, 1545 */
+#define RAFTHIP_ACT_UPDATED 2     /* the branch of raft.go:1477 ran: maybeCommit (the commit pass), then
+                                     `for r.maybeSendAppend(m.From, false)`, raft.go:1516-1519 */
+#define RAFTHIP_ACT_WAS_PAUSED 4  /* oldPaused, raft.go:1468: with UPDATED and no commit advance, sendAppend (:1505-1509) */
+#define RAFTHIP_ACT_CAUGHT_UP 8   /* with UPDATED: pr.Match == lastIndex, the leadTransferee test of raft.go:1521 */
+#define RAFTHIP_ACT_ERROR 32      /* the reference errors or panics on this call (progress.go:160, inflights.go:66-68): not applied */
+#define RAFTHIP_ACT_DEFERRED 64   /* not stepped: its Progress is named by more than RAFTHIP_STEP_LIMIT events of this batch */
+#define RAFTHIP_ACT_DROPPED 128   /* no Progress row (raft.go:1327-1331) or not an event type */
+#define RAFTHIP_STEP_LIMIT 64
+
+/* Allocate the per-peer planes: Next, State, MsgAppFlowPaused, PendingSnapshot
+ * and an Inflights ring of max_inflight entries per Progress (Config.MaxInflightMsgs,
+ * raft.go:205-211; max_inflight_bytes = Config.MaxInflightBytes, 0 = no limit,
+ * raft.go:212-220; tracker.NewInflights, tracker/inflights.go:46-51).  Device
+ * memory: S * stride * (16 * max_inflight + 33) bytes.  Once per engine. */
+int rafthip_progress_config(rafthip_engine *e, uint32_t max_inflight, uint64_t max_inflight_bytes);
+
+/* (Re)initialise Progress rows — what raft.reset (raft.go:774-784), becomeLeader
+ * (raft.go:915-920) or a conf change (confchange/confchange.go:231-272) leave
+ * behind: state[s*src_stride + g] = RAFTHIP_STATE_* | RAFTHIP_PROGRESS_PAUSED,
+ * next, pending (NULL = 0).  The Inflights of the range are emptied
+ * (Progress.ResetState, tracker/progress.go:102-107).  Match is rafthip_upload_match's. */
+int rafthip_upload_progress(rafthip_engine *e, uint64_t first, uint64_t count, const uint8_t *state,
+                            const uint64_t *next, const uint64_t *pending, uint64_t src_stride);
+/* Any destination may be NULL.  infl_meta = Inflights.start | Inflights.count << 16,
+ * infl_bytes = Inflights.bytes (tracker/inflights.go:28-40). */
+int rafthip_read_progress(rafthip_engine *e, uint64_t first, uint64_t count, uint8_t *state, uint64_t *next,
+                          uint64_t *pending, uint32_t *infl_meta, uint64_t *infl_bytes, uint64_t dst_stride);
+/* The Inflights rings as laid out in the reference's buffer: entry k of slot s of
+ * group first+g at [(k*S + s)*stride + g], k < max(max_inflight, 1). */
+int rafthip_upload_inflights(rafthip_engine *e, uint64_t first, uint64_t count, const uint32_t *infl_meta,
+                             const uint64_t *infl_bytes, const uint64_t *ring_index, const uint64_t *ring_bytes,
+                             uint64_t src_stride);
+int rafthip_read_inflights(rafthip_engine *e, uint64_t first, uint64_t count, uint64_t *ring_index,
+                           uint64_t *ring_bytes, uint64_t dst_stride);
+/* raftLog.firstIndex() per group, for the StateSnapshot exit of raft.go:1481 (default 0). */
+int rafthip_upload_first_index(rafthip_engine *e, uint64_t first, uint64_t count, const uint64_t *first_index);
+
+/* stepLeader's Progress branches for a batch of events — raft.go:1333-1586 —
+ * with the send-side bookkeeping of maybeSendAppend (raft.go:645,653) as events
+ * of the same stream:
+ *   MsgAppResp        RecentActive; Reject: MaybeDecrTo(m.Index, aux) and, from
+ *                     StateReplicate, BecomeProbe (raft.go:1339-1466; aux = nextProbeIdx,
+ *                     i.e. RejectHint after raft.go:1362-1459's findConflictByTerm on the
+ *                     host's log); else MaybeUpdate and Probe->Replicate,
+ *                     Snapshot->Probe->Replicate (needs firstIndex) or Inflights.FreeLE
+ *                     (raft.go:1467-1526)
+ *   MsgHeartbeatResp  RecentActive, MsgAppFlowPaused = false, ReadIndex ack with
+ *                     RAFTHIP_MSGF_READ_CTX (raft.go:1527-1561)
+ *   MsgSnapStatus, MsgUnreachable, RAFTHIP_MSG_SENT_APP, RAFTHIP_MSG_SENT_SNAP   as above
+ *   RAFTHIP_MSG_APPENDED  term_last = max(term_last, index); every such record of
+ *                     the batch applies BEFORE its responses
+ * Events of one Progress are stepped in stream order, events of different
+ * Progress rows are independent on this path, so the result equals stepping
+ * the batch one message at a time with every send deferred to the end of the
+ * batch (the host performs the sends the action bytes ask for, and reports
+ * them as SENT records of a later batch).  lastIndex is term_last
+ * (rafthip_upload_term_range).  aux (one uint64 per event) may be NULL = all 0;
+ * actions (one RAFTHIP_ACT_* byte set per event) may be NULL; both may be host or
+ * device memory.  Requires rafthip_progress_config.  n <= 2^31. */
+int rafthip_step_progress(rafthip_engine *e, const rafthip_msg *msgs, const uint64_t *aux, uint64_t n,
+                          uint8_t *actions);
+
 /* ProgressTracker.Committed for every group — tracker/tracker.go:179-181 =
  * JointConfig.CommittedIndex (quorum/joint.go:49-56) over
  * MajorityConfig.CommittedIndex (quorum/majority.go:126-172) with

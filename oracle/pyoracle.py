@@ -21,8 +21,8 @@ ACK_DTYPE = np.dtype([("group", "<u4"), ("slot", "<u4"), ("index", "<u8")])
 
 def build(force=False):
     so = os.path.join(_HERE, "liboracle.so")
-    src = os.path.join(_HERE, "quorum_oracle.c")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("quorum_oracle.c", "progress_oracle.c")]
+    if force or not os.path.exists(so) or any(os.path.getmtime(so) < os.path.getmtime(src) for src in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
     return so
 
@@ -79,6 +79,31 @@ def lib():
         L.oracle_step_wire_msgs.restype = None
         L.oracle_step_wire_msgs.argtypes = [C.c_uint64, C.c_int, vp, C.c_uint64, vp, vp, C.c_int, vp, C.c_uint64,
                                             vp, vp, vp, vp, C.c_uint64, vp, vp, C.c_uint64, vp, vp, vp]
+        L.oracle_progress_new.restype = vp
+        L.oracle_progress_new.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_uint64]
+        L.oracle_progress_free.restype = None
+        L.oracle_progress_free.argtypes = [vp]
+        L.oracle_progress_get.restype = None
+        L.oracle_progress_get.argtypes = [vp, vp]
+        L.oracle_inflights_get.restype = None
+        L.oracle_inflights_get.argtypes = [vp, vp, vp, vp]
+        L.oracle_inflights_set_start.restype = None
+        L.oracle_inflights_set_start.argtypes = [vp, C.c_int]
+        L.oracle_inflights_add.restype = C.c_int
+        L.oracle_inflights_add.argtypes = [vp, C.c_uint64, C.c_uint64]
+        L.oracle_inflights_free_le.restype = None
+        L.oracle_inflights_free_le.argtypes = [vp, C.c_uint64]
+        L.oracle_inflights_reset.restype = None
+        L.oracle_inflights_reset.argtypes = [vp]
+        L.oracle_progress_maybe_update.restype = C.c_int
+        L.oracle_progress_maybe_update.argtypes = [vp, C.c_uint64]
+        L.oracle_progress_maybe_decr_to.restype = C.c_int
+        L.oracle_progress_maybe_decr_to.argtypes = [vp, C.c_uint64, C.c_uint64]
+        L.oracle_progress_become.restype = None
+        L.oracle_progress_become.argtypes = [vp, C.c_int, C.c_uint64]
+        L.oracle_step_progress.restype = None
+        L.oracle_step_progress.argtypes = [C.c_uint64, C.c_int, C.c_uint64] + [vp] * 8 + [C.c_int, C.c_uint64, vp, vp,
+                                           C.c_int, vp, vp, vp, vp, C.c_uint64, C.c_uint32, vp]
         L.oracle_batch_check_quorum.restype = None
         L.oracle_batch_check_quorum.argtypes = [C.c_uint64, C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp]
         L.oracle_batch_heartbeat_commit.restype = None
@@ -388,3 +413,93 @@ class CpuBaseline:
         if self.h:
             lib().oracle_bench_destroy(self.h)
             self.h = None
+
+
+# ---- tracker.Progress / tracker.Inflights (progress_oracle.c) --------------------------------
+
+STATE_PROBE, STATE_REPLICATE, STATE_SNAPSHOT = 0, 1, 2
+STATE_NAMES = {"StateProbe": 0, "StateReplicate": 1, "StateSnapshot": 2}
+EV_APP_RESP, EV_HEARTBEAT_RESP, EV_UNREACHABLE, EV_SNAP_STATUS = 4, 9, 10, 11
+EV_APPENDED, EV_SENT_APP, EV_SENT_SNAP = 0xF0, 0xF1, 0xF2
+ACT_SEND_APPEND, ACT_UPDATED, ACT_WAS_PAUSED, ACT_CAUGHT_UP, ACT_ERROR, ACT_DEFERRED, ACT_DROPPED = 1, 2, 4, 8, 32, 64, 128
+STEP_LIMIT = 64  # events per Progress per batch the engine steps (more: deferred)
+
+
+class Progress:
+    """One tracker.Progress (tracker/progress.go:30-98) with its Inflights, by handle."""
+
+    def __init__(self, state=0, match=0, next=0, pending=0, paused=False, inflight_size=256, inflight_max_bytes=0):
+        self._h = lib().oracle_progress_new(state, match, next, pending, int(paused), inflight_size, inflight_max_bytes)
+        self._size = inflight_size
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().oracle_progress_free(self._h)
+            self._h = None
+
+    def get(self):
+        out = np.zeros(7, dtype=np.uint64)
+        lib().oracle_progress_get(self._h, _vp(out))
+        return {"state": int(out[0]), "match": int(out[1]), "next": int(out[2]), "pending": int(out[3]),
+                "paused": bool(out[4]), "is_paused": bool(out[5])}
+
+    def inflights(self):
+        out = np.zeros(5, dtype=np.uint64)
+        idx = np.zeros(max(self._size, 1), dtype=np.uint64)
+        by = np.zeros(max(self._size, 1), dtype=np.uint64)
+        lib().oracle_inflights_get(self._h, _vp(out), _vp(idx), _vp(by))
+        return {"start": int(out[0]), "count": int(out[1]), "bytes": int(out[2]), "size": int(out[3]),
+                "full": bool(out[4]), "index": idx[:self._size].tolist(), "sizes": by[:self._size].tolist()}
+
+    def set_start(self, start):
+        lib().oracle_inflights_set_start(self._h, start)
+
+    def add(self, index, nbytes):
+        return int(lib().oracle_inflights_add(self._h, index, nbytes))
+
+    def free_le(self, to):
+        lib().oracle_inflights_free_le(self._h, to)
+
+    def reset_inflights(self):
+        lib().oracle_inflights_reset(self._h)
+
+    def maybe_update(self, n):
+        return bool(lib().oracle_progress_maybe_update(self._h, n))
+
+    def maybe_decr_to(self, rejected, hint):
+        return bool(lib().oracle_progress_maybe_decr_to(self._h, rejected, hint))
+
+    def become(self, state, snapshoti=0):
+        lib().oracle_progress_become(self._h, state, snapshoti)
+
+
+def progress_planes(S, G, cap):
+    """Zeroed [slot][group] planes of the per-peer replication state (every Progress in
+    StateProbe, Match 0, Next 0, empty Inflights of capacity cap)."""
+    return {"match": np.zeros((S, G), dtype=np.uint64), "next": np.zeros((S, G), dtype=np.uint64),
+            "pstate": np.zeros((S, G), dtype=np.uint8), "pending": np.zeros((S, G), dtype=np.uint64),
+            "infl_meta": np.zeros((S, G), dtype=np.uint32), "infl_bytes": np.zeros((S, G), dtype=np.uint64),
+            "ring_index": np.zeros((max(cap, 1), S, G), dtype=np.uint64),
+            "ring_bytes": np.zeros((max(cap, 1), S, G), dtype=np.uint64)}
+
+
+def step_progress(pl, cap, max_bytes, active, acks, last_index, first_index, msgs, aux=None, limit=STEP_LIMIT):
+    """stepLeader's Progress branches for a batch of events, in stream order per Progress;
+    mutates the planes, active, acks, last_index.  Returns the per-event action bytes."""
+    S, G = pl["match"].shape
+    for k in ("match", "next", "pstate", "pending", "infl_meta", "infl_bytes", "ring_index", "ring_bytes"):
+        assert pl[k].flags["C_CONTIGUOUS"] and pl[k].shape[-2:] == (S, G), k
+    assert pl["ring_index"].shape[0] == max(cap, 1)
+    msgs = _chk(msgs)
+    n = len(msgs)
+    if aux is not None:
+        aux = _chk(aux, np.uint64)
+        assert len(aux) == n
+    actions = np.zeros(n, dtype=np.uint8)
+    lib().oracle_step_progress(G, S, G, _vp(pl["match"]), _vp(pl["next"]), _vp(pl["pstate"]), _vp(pl["pending"]),
+                               _vp(pl["infl_meta"]), _vp(pl["infl_bytes"]), _vp(pl["ring_index"]),
+                               _vp(pl["ring_bytes"]), cap, max_bytes, _vp(_chk(active)), _vp(_chk(acks)),
+                               active.dtype.itemsize, _vp(_chk(last_index, np.uint64)),
+                               _vp(_chk(first_index, np.uint64)), _vp(msgs), _vp(aux) if aux is not None else None,
+                               n, limit, _vp(actions))
+    return actions

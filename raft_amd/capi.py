@@ -40,7 +40,14 @@ SYMBOLS = [
     "rafthip_read_active", "rafthip_read_acks", "rafthip_read_term_range",
     "rafthip_committed_in_term", "rafthip_read_committed_in_term",
     "rafthip_upload_ids", "rafthip_upload_term", "rafthip_upload_read_ctx", "rafthip_ingest_wire",
+    "rafthip_progress_config", "rafthip_upload_progress", "rafthip_read_progress", "rafthip_upload_inflights",
+    "rafthip_read_inflights", "rafthip_upload_first_index", "rafthip_step_progress",
 ]
+
+STATE_PROBE, STATE_REPLICATE, STATE_SNAPSHOT, PROGRESS_PAUSED = 0, 1, 2, 4
+MSG_UNREACHABLE, MSG_SNAP_STATUS, MSG_SENT_APP, MSG_SENT_SNAP = 10, 11, 0xF1, 0xF2
+ACT_SEND_APPEND, ACT_UPDATED, ACT_WAS_PAUSED, ACT_CAUGHT_UP, ACT_ERROR, ACT_DEFERRED, ACT_DROPPED = 1, 2, 4, 8, 32, 64, 128
+STEP_LIMIT = 64
 
 
 WIRE_STATUSES = 8
@@ -149,6 +156,13 @@ def load_library():
         "rafthip_upload_term": (i32, [vp, u64, u64, vp]),
         "rafthip_upload_read_ctx": (i32, [vp, u64, u64, vp, vp]),
         "rafthip_ingest_wire": (i32, [vp, vp, vp, vp, u64, vp, vp, vp]),
+        "rafthip_progress_config": (i32, [vp, u32, u64]),
+        "rafthip_upload_progress": (i32, [vp, u64, u64, vp, vp, vp, u64]),
+        "rafthip_read_progress": (i32, [vp, u64, u64, vp, vp, vp, vp, vp, u64]),
+        "rafthip_upload_inflights": (i32, [vp, u64, u64, vp, vp, vp, vp, u64]),
+        "rafthip_read_inflights": (i32, [vp, u64, u64, vp, vp, u64]),
+        "rafthip_upload_first_index": (i32, [vp, u64, u64, vp]),
+        "rafthip_step_progress": (i32, [vp, vp, vp, u64, vp]),
     }
     assert sorted(sig) == sorted(SYMBOLS)
     for name, (res, args) in sig.items():
@@ -340,6 +354,50 @@ class Engine:
         _check(self._L.rafthip_ingest_wire(self._h, _ptr(data), _ptr(offsets), _ptr(groups), n, _ptr(msgs),
                                            _ptr(status), _ptr(counts)))
         return msgs, status, counts
+
+    def progress_config(self, max_inflight, max_inflight_bytes=0):
+        _check(self._L.rafthip_progress_config(self._h, max_inflight, max_inflight_bytes))
+        self.inflight_cap = max_inflight
+
+    def upload_progress(self, state, next, pending=None, first=0, count=None):
+        """state u8 [S][count] (STATE_* | PROGRESS_PAUSED), next / pending u64 [S][count]; empties the Inflights."""
+        first, count = self._range(first, count)
+        assert state.shape == (self.S, count) and next.shape == (self.S, count)
+        _check(self._L.rafthip_upload_progress(self._h, first, count, _ptr(state), _ptr(next), _ptr(pending), count))
+
+    def upload_inflights(self, infl_meta, infl_bytes, ring_index, ring_bytes, first=0, count=None):
+        first, count = self._range(first, count)
+        assert ring_index.shape == (max(self.inflight_cap, 1), self.S, count) == ring_bytes.shape
+        _check(self._L.rafthip_upload_inflights(self._h, first, count, _ptr(infl_meta), _ptr(infl_bytes),
+                                                _ptr(ring_index), _ptr(ring_bytes), count))
+
+    def upload_first_index(self, first_index, first=0, count=None):
+        first, count = self._range(first, count)
+        _check(self._L.rafthip_upload_first_index(self._h, first, count, _ptr(first_index)))
+
+    def read_progress(self, first=0, count=None, rings=True):
+        """The per-peer planes as a dict of [slot][group] arrays (rings: [entry][slot][group])."""
+        first, count = self._range(first, count)
+        S, cap = self.S, max(self.inflight_cap, 1)
+        pl = {"pstate": np.empty((S, count), dtype=np.uint8), "next": np.empty((S, count), dtype=np.uint64),
+              "pending": np.empty((S, count), dtype=np.uint64), "infl_meta": np.empty((S, count), dtype=np.uint32),
+              "infl_bytes": np.empty((S, count), dtype=np.uint64)}
+        _check(self._L.rafthip_read_progress(self._h, first, count, _ptr(pl["pstate"]), _ptr(pl["next"]),
+                                             _ptr(pl["pending"]), _ptr(pl["infl_meta"]), _ptr(pl["infl_bytes"]), count))
+        if rings:
+            pl["ring_index"] = np.empty((cap, S, count), dtype=np.uint64)
+            pl["ring_bytes"] = np.empty((cap, S, count), dtype=np.uint64)
+            _check(self._L.rafthip_read_inflights(self._h, first, count, _ptr(pl["ring_index"]), _ptr(pl["ring_bytes"]),
+                                                  count))
+        return pl
+
+    def step_progress(self, msgs, aux=None, n=None, want_actions=True):
+        """Events (MSG_DTYPE records or a device pointer) -> action bytes (numpy), in stream order per Progress."""
+        if n is None:
+            n = len(msgs)
+        actions = np.zeros(n, dtype=np.uint8) if want_actions else None
+        _check(self._L.rafthip_step_progress(self._h, _ptr(msgs), _ptr(aux), n, _ptr(actions)))
+        return actions
 
     def heartbeat_commit(self, first=0, count=None, download=True):
         first, count = self._range(first, count)

@@ -10,6 +10,7 @@
 
 #include "kernels.h"
 #include "wire.h"
+#include "progress.h"
 #include "rafthip.h"
 
 using namespace rafthip;
@@ -112,8 +113,15 @@ struct rafthip_engine {
     u64* read_ctx = nullptr;       // pending ReadIndex context (<= 8 bytes, little-endian) ...
     uint8_t* read_ctx_len = nullptr;  // ... and its length, 0 = none
     u64* d_wire_counts = nullptr;  // [RAFTHIP_WIRE_STATUSES]
-    void* wire_buf[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // staging: bytes, offsets, groups, out msgs, out status
-    size_t wire_cap[5] = {0, 0, 0, 0, 0};
+    // growable staging: wire bytes, offsets, groups, out msgs, out status; progress aux, actions, prev links
+    void* wire_buf[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t wire_cap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+
+    // per-peer replication state (rafthip_progress_config)
+    bool prog = false;
+    ProgPlanes pp{};
+    u32* prog_head = nullptr;   // [S][stride] list heads of rafthip_step_progress, zero between calls
+    u64* first_index = nullptr; // raftLog.firstIndex() per group
 
     rafthip_stats_t stats{};
 };
@@ -598,7 +606,10 @@ int rafthip_destroy(rafthip_engine* e) {
                     e->ack_result, e->stage,   e->packed,       e->counts,   e->offsets,  e->ack_buf,
                     e->d_rejected, e->self_mask, e->term_first, e->term_last, e->hb_commit, e->in_term,
                     e->ids, e->cur_term, e->read_ctx, e->read_ctx_len, e->d_wire_counts,
-                    e->wire_buf[0], e->wire_buf[1], e->wire_buf[2], e->wire_buf[3], e->wire_buf[4]};
+                    e->wire_buf[0], e->wire_buf[1], e->wire_buf[2], e->wire_buf[3], e->wire_buf[4],
+                    e->wire_buf[5], e->wire_buf[6], e->wire_buf[7], e->pp.next, e->pp.pstate, e->pp.pending,
+                    e->pp.infl_meta, e->pp.infl_bytes, e->pp.ring_index, e->pp.ring_bytes, e->prog_head,
+                    e->first_index};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (e->h_scalar) (void)hipHostFree(e->h_scalar);
@@ -963,6 +974,192 @@ int rafthip_ingest_wire(rafthip_engine* e, const uint8_t* bytes, const uint64_t*
     if (status_counts) {
         HIP_TRY(hipMemcpyAsync(status_counts, e->d_wire_counts, RAFTHIP_WIRE_STATUSES * sizeof(u64),
                                hipMemcpyDeviceToHost, e->stream));
+        wait = true;
+    }
+    if (wait) HIP_TRY(hipStreamSynchronize(e->stream));
+    e->stats.msgs_ingested += n;
+    return RAFTHIP_OK;
+}
+
+// ---- per-peer replication state (tracker.Progress, tracker.Inflights) --------
+
+static_assert(kStepLimit == RAFTHIP_STEP_LIMIT && kActSendAppend == RAFTHIP_ACT_SEND_APPEND &&
+                  kActUpdated == RAFTHIP_ACT_UPDATED && kActWasPaused == RAFTHIP_ACT_WAS_PAUSED &&
+                  kActCaughtUp == RAFTHIP_ACT_CAUGHT_UP && kActError == RAFTHIP_ACT_ERROR &&
+                  kActDeferred == RAFTHIP_ACT_DEFERRED && kActDropped == RAFTHIP_ACT_DROPPED &&
+                  kEvUnreachable == RAFTHIP_MSG_UNREACHABLE && kEvSnapStatus == RAFTHIP_MSG_SNAP_STATUS &&
+                  kEvSentApp == RAFTHIP_MSG_SENT_APP && kEvSentSnap == RAFTHIP_MSG_SENT_SNAP &&
+                  kStateProbe == RAFTHIP_STATE_PROBE && kStateReplicate == RAFTHIP_STATE_REPLICATE &&
+                  kStateSnapshot == RAFTHIP_STATE_SNAPSHOT,
+              "progress constants");
+
+static int need_progress(const rafthip_engine* e) {
+    if (!e) return fail(RAFTHIP_EINVAL, "engine is NULL");
+    if (!e->prog) return fail(RAFTHIP_EINVAL, "rafthip_progress_config must come first");
+    return RAFTHIP_OK;
+}
+
+int rafthip_progress_config(rafthip_engine* e, uint32_t max_inflight, uint64_t max_inflight_bytes) {
+    if (!e) return fail(RAFTHIP_EINVAL, "engine is NULL");
+    if (max_inflight > 65535) return fail(RAFTHIP_EINVAL, "max_inflight %u > 65535", max_inflight);
+    if (e->prog) {
+        if (e->pp.cap == max_inflight && e->pp.max_bytes == max_inflight_bytes) return RAFTHIP_OK;
+        return fail(RAFTHIP_EINVAL, "the Inflights limits of an engine are fixed once configured");
+    }
+    DeviceGuard guard(e->device);
+    const size_t cells = (size_t)e->S * e->stride;
+    const size_t ring = (size_t)(max_inflight ? max_inflight : 1) * cells * sizeof(u64);
+    int rc;
+    if ((rc = ensure(e, e->pp.next, cells * sizeof(u64)))) return rc;
+    if ((rc = ensure(e, e->pp.pstate, cells))) return rc;
+    if ((rc = ensure(e, e->pp.pending, cells * sizeof(u64)))) return rc;
+    if ((rc = ensure(e, e->pp.infl_meta, cells * sizeof(u32)))) return rc;
+    if ((rc = ensure(e, e->pp.infl_bytes, cells * sizeof(u64)))) return rc;
+    if ((rc = ensure(e, e->pp.ring_index, ring))) return rc;
+    if ((rc = ensure(e, e->pp.ring_bytes, ring))) return rc;
+    if ((rc = ensure(e, e->prog_head, cells * sizeof(u32)))) return rc;
+    if ((rc = ensure(e, e->first_index, (size_t)e->stride * sizeof(u64)))) return rc;
+    if ((rc = ensure(e, e->term_last, (size_t)e->stride * sizeof(u64)))) return rc;
+    if ((rc = ensure(e, e->term_first, (size_t)e->stride * sizeof(u64)))) return rc;
+    e->pp.match = e->match;
+    e->pp.stride = e->stride;
+    e->pp.plane = (u64)cells;
+    e->pp.cap = max_inflight;
+    e->pp.max_bytes = max_inflight_bytes;
+    e->prog = true;
+    return RAFTHIP_OK;
+}
+
+int rafthip_upload_progress(rafthip_engine* e, uint64_t first, uint64_t count, const uint8_t* state,
+                            const uint64_t* next, const uint64_t* pending, uint64_t src_stride) {
+    int rc = need_progress(e);
+    if (rc || (rc = check_range(e, first, count))) return rc;
+    if (!state || !next) return fail(RAFTHIP_EINVAL, "state/next is NULL");
+    if (src_stride < count) return fail(RAFTHIP_EINVAL, "src_stride %llu < count %llu", (u64)src_stride, (u64)count);
+    if (count == 0) return RAFTHIP_OK;
+    DeviceGuard guard(e->device);
+    const u64 st = e->stride;
+    if ((rc = copy_rows(e, e->pp.pstate + first, st, state, src_stride, count, e->S))) return rc;
+    if ((rc = copy_rows(e, e->pp.next + first, st * 8, next, src_stride * 8, count * 8, e->S))) return rc;
+    if (pending) {
+        if ((rc = copy_rows(e, e->pp.pending + first, st * 8, pending, src_stride * 8, count * 8, e->S))) return rc;
+    } else {
+        HIP_TRY(hipMemset2DAsync(e->pp.pending + first, st * 8, 0, count * 8, e->S, e->stream));
+    }
+    hipLaunchKernelGGL(k_progress_clear_inflights, dim3((u32)((count + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                       e->stream, e->pp.infl_meta, e->pp.infl_bytes, st, (u64)first, (u64)count, e->S);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    e->stats.bytes_uploaded += count * e->S * (pending ? 17 : 9);
+    return RAFTHIP_OK;
+}
+
+int rafthip_read_progress(rafthip_engine* e, uint64_t first, uint64_t count, uint8_t* state, uint64_t* next,
+                          uint64_t* pending, uint32_t* infl_meta, uint64_t* infl_bytes, uint64_t dst_stride) {
+    int rc = need_progress(e);
+    if (rc || (rc = check_range(e, first, count))) return rc;
+    if (dst_stride < count) return fail(RAFTHIP_EINVAL, "dst_stride %llu < count %llu", (u64)dst_stride, (u64)count);
+    DeviceGuard guard(e->device);
+    const u64 st = e->stride;
+    if (state && (rc = copy_rows(e, state, dst_stride, e->pp.pstate + first, st, count, e->S))) return rc;
+    if (next && (rc = copy_rows(e, next, dst_stride * 8, e->pp.next + first, st * 8, count * 8, e->S))) return rc;
+    if (pending && (rc = copy_rows(e, pending, dst_stride * 8, e->pp.pending + first, st * 8, count * 8, e->S)))
+        return rc;
+    if (infl_meta && (rc = copy_rows(e, infl_meta, dst_stride * 4, e->pp.infl_meta + first, st * 4, count * 4, e->S)))
+        return rc;
+    if (infl_bytes &&
+        (rc = copy_rows(e, infl_bytes, dst_stride * 8, e->pp.infl_bytes + first, st * 8, count * 8, e->S)))
+        return rc;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    e->stats.bytes_downloaded += count * e->S * ((state ? 1 : 0) + (next ? 8 : 0) + (pending ? 8 : 0) +
+                                                 (infl_meta ? 4 : 0) + (infl_bytes ? 8 : 0));
+    return RAFTHIP_OK;
+}
+
+int rafthip_upload_inflights(rafthip_engine* e, uint64_t first, uint64_t count, const uint32_t* infl_meta,
+                             const uint64_t* infl_bytes, const uint64_t* ring_index, const uint64_t* ring_bytes,
+                             uint64_t src_stride) {
+    int rc = need_progress(e);
+    if (rc || (rc = check_range(e, first, count))) return rc;
+    if (!infl_meta || !infl_bytes || !ring_index || !ring_bytes) return fail(RAFTHIP_EINVAL, "a source is NULL");
+    if (src_stride < count) return fail(RAFTHIP_EINVAL, "src_stride %llu < count %llu", (u64)src_stride, (u64)count);
+    DeviceGuard guard(e->device);
+    const u64 st = e->stride, rows = (u64)(e->pp.cap ? e->pp.cap : 1) * e->S;
+    if ((rc = copy_rows(e, e->pp.infl_meta + first, st * 4, infl_meta, src_stride * 4, count * 4, e->S))) return rc;
+    if ((rc = copy_rows(e, e->pp.infl_bytes + first, st * 8, infl_bytes, src_stride * 8, count * 8, e->S))) return rc;
+    if ((rc = copy_rows(e, e->pp.ring_index + first, st * 8, ring_index, src_stride * 8, count * 8, rows))) return rc;
+    if ((rc = copy_rows(e, e->pp.ring_bytes + first, st * 8, ring_bytes, src_stride * 8, count * 8, rows))) return rc;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    e->stats.bytes_uploaded += count * (e->S * 12 + rows * 16);
+    return RAFTHIP_OK;
+}
+
+int rafthip_read_inflights(rafthip_engine* e, uint64_t first, uint64_t count, uint64_t* ring_index,
+                           uint64_t* ring_bytes, uint64_t dst_stride) {
+    int rc = need_progress(e);
+    if (rc || (rc = check_range(e, first, count))) return rc;
+    if (dst_stride < count) return fail(RAFTHIP_EINVAL, "dst_stride %llu < count %llu", (u64)dst_stride, (u64)count);
+    DeviceGuard guard(e->device);
+    const u64 st = e->stride, rows = (u64)(e->pp.cap ? e->pp.cap : 1) * e->S;
+    if (ring_index && (rc = copy_rows(e, ring_index, dst_stride * 8, e->pp.ring_index + first, st * 8, count * 8, rows)))
+        return rc;
+    if (ring_bytes && (rc = copy_rows(e, ring_bytes, dst_stride * 8, e->pp.ring_bytes + first, st * 8, count * 8, rows)))
+        return rc;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    e->stats.bytes_downloaded += count * rows * ((ring_index ? 8 : 0) + (ring_bytes ? 8 : 0));
+    return RAFTHIP_OK;
+}
+
+int rafthip_upload_first_index(rafthip_engine* e, uint64_t first, uint64_t count, const uint64_t* first_index) {
+    int rc = check_range(e, first, count);
+    if (rc) return rc;
+    if (!first_index) return fail(RAFTHIP_EINVAL, "first_index is NULL");
+    DeviceGuard guard(e->device);
+    if ((rc = ensure(e, e->first_index, (size_t)e->stride * sizeof(u64)))) return rc;
+    HIP_TRY(hipMemcpyAsync(e->first_index + first, first_index, count * 8, hipMemcpyDefault, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    e->stats.bytes_uploaded += count * 8;
+    return RAFTHIP_OK;
+}
+
+int rafthip_step_progress(rafthip_engine* e, const rafthip_msg* msgs, const uint64_t* aux, uint64_t n,
+                          uint8_t* actions) {
+    int rc = need_progress(e);
+    if (rc) return rc;
+    if (n == 0) return RAFTHIP_OK;
+    if (!msgs) return fail(RAFTHIP_EINVAL, "msgs is NULL");
+    if (n > (1ull << 31)) return fail(RAFTHIP_EINVAL, "more than 2^31 events in one batch: split it");
+    DeviceGuard guard(e->device);
+    const size_t mb = (size_t)e->stride * e->mbytes;
+    if ((rc = ensure(e, e->active, mb))) return rc;
+    if ((rc = ensure(e, e->acks, mb))) return rc;
+    const void* d_recs = nullptr;
+    bool staged = false;
+    if ((rc = stage_records(e, msgs, n, &d_recs, &staged))) return rc;
+    const void* d_aux = nullptr;
+    if (aux && (rc = wire_input(e, 5, aux, (size_t)n * sizeof(u64), &d_aux))) return rc;
+    const bool act_host = !actions || !is_device_ptr(actions);
+    uint8_t* d_act = actions;
+    if (act_host) {
+        if ((rc = wire_reserve(e, 6, (size_t)n))) return rc;
+        d_act = static_cast<uint8_t*>(e->wire_buf[6]);
+    }
+    if ((rc = wire_reserve(e, 7, (size_t)n * sizeof(u32)))) return rc;
+    u32* prev = static_cast<u32*>(e->wire_buf[7]);
+    const u32 blocks = (u32)((n + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(k_progress_link, dim3(blocks), dim3(kBlock), 0, e->stream, static_cast<const Msg*>(d_recs),
+                       (u32)n, e->G, e->S, e->stride, e->prog_head, prev, e->term_last, d_act);
+    HIP_TRY(hipGetLastError());
+    e->pp.match = e->match;
+    hipLaunchKernelGGL(k_progress_apply, dim3(blocks), dim3(kBlock), 0, e->stream, static_cast<const Msg*>(d_recs),
+                       static_cast<const u64*>(d_aux), (u32)n, e->G, e->S, e->pp, e->prog_head,
+                       static_cast<const u32*>(prev), e->active, e->acks, e->mbytes,
+                       static_cast<const u64*>(e->term_last), static_cast<const u64*>(e->first_index), d_act);
+    HIP_TRY(hipGetLastError());
+    bool wait = staged || (aux && d_aux != aux);
+    if (actions && act_host) {
+        HIP_TRY(hipMemcpyAsync(actions, d_act, (size_t)n, hipMemcpyDeviceToHost, e->stream));
+        e->stats.bytes_downloaded += n;
         wait = true;
     }
     if (wait) HIP_TRY(hipStreamSynchronize(e->stream));

@@ -1,0 +1,189 @@
+"""GPU parity for the per-peer replication state:
+rafthip_step_progress = tracker.Progress + tracker.Inflights driven by
+stepLeader's branches (raft.go:1333-1586), in stream order per Progress.
+Bit-exact vs oracle/progress_oracle.c, which tests/test_progress_cpu.py pins to
+the reference's own tables and scenarios; through the C ABI."""
+import numpy as np
+import pytest
+
+import progress_util as pu
+import raft_amd
+from oracle import pyoracle as po
+from raft_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+FX = pu.load_fixture()
+KEYS = ("pstate", "next", "pending", "infl_meta", "infl_bytes", "ring_index", "ring_bytes")
+
+
+def upload_state(e, pl, cap, max_bytes, active, acks, last, first):
+    e.progress_config(cap, max_bytes)
+    e.upload_match(pl["match"])
+    e.upload_progress(pl["pstate"], pl["next"], pl["pending"])
+    e.upload_inflights(pl["infl_meta"], pl["infl_bytes"], pl["ring_index"], pl["ring_bytes"])
+    e.upload_active(active)
+    e.upload_acks(acks)
+    e.upload_term_range(np.zeros(len(last), dtype=np.uint64), last)
+    e.upload_first_index(first)
+
+
+def assert_state(e, pl, active, acks, last):
+    got = e.read_progress()
+    for k in KEYS:
+        assert np.array_equal(got[k], pl[k]), k
+    assert np.array_equal(e.read_match(), pl["match"])
+    assert np.array_equal(e.read_active(), active)
+    assert np.array_equal(e.read_acks(), acks)
+    assert np.array_equal(e.read_term_range()[1], last)
+
+
+def test_constants_match_the_oracle():
+    for name in ("ACT_SEND_APPEND", "ACT_UPDATED", "ACT_WAS_PAUSED", "ACT_CAUGHT_UP", "ACT_ERROR", "ACT_DEFERRED",
+                 "ACT_DROPPED", "STEP_LIMIT", "STATE_PROBE", "STATE_REPLICATE", "STATE_SNAPSHOT"):
+        assert getattr(capi, name) == getattr(po, name), name
+    assert (capi.MSG_UNREACHABLE, capi.MSG_SNAP_STATUS, capi.MSG_SENT_APP, capi.MSG_SENT_SNAP) == (
+        po.EV_UNREACHABLE, po.EV_SNAP_STATUS, po.EV_SENT_APP, po.EV_SENT_SNAP)
+
+
+@pytest.mark.parametrize("k", range(len(FX["scenarios"])))
+def test_reference_scenarios(k):
+    """tests/golden/progress.json on the engine: every step as its own batch (expected
+    state and actions from the reference's tests), then the whole scenario as one batch."""
+    sc = FX["scenarios"][k]
+    steps = pu.scenario_steps(sc)
+    cap, mb = sc["cap"], sc["max_bytes"]
+    S, G, slot, group = 3, 5, 1, 3  # the scenario's Progress sits in the middle of a small engine
+    pl = pu.init_planes(sc, S, G, slot, group)
+    active, acks = pu.mask_planes(S, G)
+    last = np.full(G, sc["last_index"], dtype=np.uint64)
+    first = np.full(G, sc["first_index"], dtype=np.uint64)
+    recs, auxs = [], []
+    with raft_amd.Engine(G, S) as e:
+        upload_state(e, pl, cap, mb, active, acks, last, first)
+        for i, st in enumerate(steps):
+            m, aux = pu.event(st, group, slot)
+            recs.append(m)
+            auxs.append(aux)
+            act = e.step_progress(m, aux)
+            pu.check_actions(st, int(act[0]), (sc["src"], i))
+            got = e.read_progress()
+            got["match"] = e.read_match()
+            pu.check_expect(st, pu.cell_state(got, cap, mb, slot, group), (sc["src"], i))
+        final = e.read_progress()
+        final["match"] = e.read_match()
+        if len(steps) <= capi.STEP_LIMIT and not any(st["ev"] == "appended" for st in steps):
+            upload_state(e, pl, cap, mb, active, acks, last, first)
+            e.step_progress(np.concatenate(recs), np.concatenate(auxs))
+            again = e.read_progress()
+            for key in KEYS:
+                assert np.array_equal(again[key], final[key]), key
+            assert np.array_equal(e.read_match(), final["match"])
+        # untouched cells stay untouched
+        other = np.ones((S, G), dtype=bool)
+        other[slot, group] = False
+        assert np.array_equal(final["next"][other], pl["next"][other])
+
+
+@pytest.mark.parametrize("S,cap,mb,hot", [(3, 4, 0, 0), (5, 4, 150, 25), (9, 1, 0, 10), (16, 8, 300, 40), (33, 3, 0, 5),
+                                           (64, 2, 60, 5), (5, 0, 0, 10)])
+def test_random_streams(S, cap, mb, hot):
+    rng = np.random.default_rng(1500 + S)
+    G, n = 2003, 40000
+    pl = pu.random_planes(rng, S, G, cap, mb)
+    msgs, aux = pu.random_events(rng, n, S, G, pl, hot_cells=hot)
+    last = rng.integers(0, 1 << 20, size=G).astype(np.uint64)
+    first = rng.integers(0, 1 << 19, size=G).astype(np.uint64)
+    active, acks = pu.mask_planes(S, G)
+    active[:] = rng.integers(0, 4, size=G)
+    with raft_amd.Engine(G, S) as e:
+        upload_state(e, pl, cap, mb, active, acks, last, first)
+        act = e.step_progress(msgs, aux)
+        want = po.step_progress(pl, cap, mb, active, acks, last, first, msgs, aux)
+        assert np.array_equal(act, want)
+        assert_state(e, pl, active, acks, last)
+        seen = np.bincount(want, minlength=256)
+        assert seen[capi.ACT_UPDATED] > 0 and seen[capi.ACT_SEND_APPEND] > 0 and seen[capi.ACT_DROPPED] > 0
+        # a second batch on top (state carried on the device), device-resident inputs, no aux
+        import torch
+        msgs2, _ = pu.random_events(rng, n // 2, S, G, pl, hot_cells=hot)
+        d = torch.from_numpy(msgs2.view(np.uint8)).cuda()
+        dact = torch.zeros(len(msgs2), dtype=torch.uint8, device="cuda")
+        L = raft_amd.load_library()
+        assert L.rafthip_step_progress(e._h, d.data_ptr(), None, len(msgs2), dact.data_ptr()) == 0
+        want2 = po.step_progress(pl, cap, mb, active, acks, last, first, msgs2, None)
+        e.synchronize()
+        assert np.array_equal(dact.cpu().numpy(), want2)
+        assert_state(e, pl, active, acks, last)
+
+
+def test_long_lists_are_deferred_whole():
+    rng = np.random.default_rng(1600)
+    S, G, cap = 4, 50, 4
+    pl = pu.random_planes(rng, S, G, cap, 0)
+    n = 3000
+    msgs, aux = pu.random_events(rng, n, S, G, pl)
+    msgs["group"][:900] = 7   # 900 events on two Progress rows of group 7 ...
+    msgs["slot"][:900] = rng.integers(0, 2, size=900)
+    msgs["group"][900:964] = 8  # ... and exactly STEP_LIMIT on one of group 8
+    msgs["slot"][900:964] = 3
+    msgs["type"][900:964] = capi.MSG_HEARTBEAT_RESP
+    keep = ~((msgs["group"] == 8) & (msgs["slot"] == 3))
+    keep[900:964] = True
+    msgs, aux = msgs[keep], np.ascontiguousarray(aux[keep])
+    last = np.full(G, 1 << 19, dtype=np.uint64)
+    first = np.zeros(G, dtype=np.uint64)
+    active, acks = pu.mask_planes(S, G)
+    with raft_amd.Engine(G, S) as e:
+        upload_state(e, pl, cap, 0, active, acks, last, first)
+        act = e.step_progress(msgs, aux)
+        want = po.step_progress(pl, cap, 0, active, acks, last, first, msgs, aux)
+        assert np.array_equal(act, want)
+        assert_state(e, pl, active, acks, last)
+        g7 = (msgs["group"] == 7) & (msgs["slot"] < 2) & (want != capi.ACT_DROPPED) & (msgs["type"] != capi.MSG_APPENDED)
+        assert (want[g7] == capi.ACT_DEFERRED).all() and g7.sum() > 2 * capi.STEP_LIMIT
+        assert (want[(msgs["group"] == 8) & (msgs["slot"] == 3)] & capi.ACT_DEFERRED == 0).all()
+        # the host resubmits what was deferred, in order, in slices the engine takes
+        idx = np.flatnonzero(want == capi.ACT_DEFERRED)
+        for lo in range(0, len(idx), 60):
+            part = idx[lo:lo + 60]
+            a = e.step_progress(np.ascontiguousarray(msgs[part]), np.ascontiguousarray(aux[part]))
+            w = po.step_progress(pl, cap, 0, active, acks, last, first, np.ascontiguousarray(msgs[part]),
+                                 np.ascontiguousarray(aux[part]))
+            assert np.array_equal(a, w) and (w & capi.ACT_DEFERRED == 0).all()
+        assert_state(e, pl, active, acks, last)
+
+
+def test_requires_config_and_rejects_bad_arguments():
+    with raft_amd.Engine(8, 3) as e:
+        m = np.zeros(1, dtype=raft_amd.MSG_DTYPE)
+        with pytest.raises(raft_amd.RafthipError):
+            e.step_progress(m)
+        e.progress_config(4, 0)
+        e.progress_config(4, 0)  # same limits: fine
+        with pytest.raises(raft_amd.RafthipError):
+            e.progress_config(5, 0)
+        assert len(e.step_progress(m[:0])) == 0
+
+
+def test_leader_tick_with_progress_full_size():
+    """cfg5 shape: 2^20 groups x (7 voters + 2 learners), one tick = 1M sends + 3M responses
+    through rafthip_step_progress, then the commit pass; every plane vs the oracle."""
+    G, S, V, cap = 1 << 20, 9, 7, 4
+    rng = np.random.default_rng(0x5EED0008)
+    pl = pu.random_planes(rng, S, G, cap, 0)
+    n = 4 * G
+    msgs, aux = pu.random_events(rng, n, S, G, pl)
+    last = pl["match"].max(axis=0) + np.uint64(16)
+    first = np.maximum(pl["match"].min(axis=0), 8) - np.uint64(8)
+    active, acks = pu.mask_planes(S, G)
+    with raft_amd.Engine(G, S) as e:
+        e.set_uniform_config(V)
+        upload_state(e, pl, cap, 0, active, acks, last, first)
+        act = e.step_progress(msgs, aux)
+        e.commit()
+        want = po.step_progress(pl, cap, 0, active, acks, last, first, msgs, aux)
+        assert np.array_equal(act, want)
+        assert_state(e, pl, active, acks, last)
+        assert np.array_equal(e.read_commit(), po.batch_committed(pl["match"], uniform_voters=V, threads=0))
+        assert (want == capi.ACT_DEFERRED).sum() == 0 and (want & capi.ACT_UPDATED).any()
