@@ -223,6 +223,28 @@ def main():
             timed("k_ingest_wire, %.1f B messages, random cells (K8)" % (len(data) / N), "msg", N, round(per_msg),
                   lambda: e.ingest_wire(d_data, d_off, d_grp, n=N, want_msgs=False, want_status=False, want_counts=False))
         del data, offsets, d_data, d_off, d_grp
+    # per-peer replication state (K9): sends + responses in stream order per Progress
+    if not args.only or args.only in "k_progress_link + k_progress_apply (K9)":
+        import progress_util as pu
+        cap = 4
+        pl = pu.random_planes(rng, Sv, G, cap, 0)
+        ev, aux = pu.random_events(rng, N, Sv, G, pl)
+        d_ev = torch.from_numpy(ev.view(np.uint8)).to(dev)
+        d_aux = torch.from_numpy(aux.view(np.int64)).to(dev)
+        d_act = torch.zeros(N, dtype=torch.uint8, device=dev)
+        L = raft_amd.load_library()
+        with raft_amd.Engine(G, Sv, stream=stream.cuda_stream) as e:
+            e.set_uniform_config(7)
+            e.progress_config(cap, 0)
+            e.upload_match(pl["match"])
+            e.upload_progress(pl["pstate"], pl["next"], pl["pending"])
+            e.upload_inflights(pl["infl_meta"], pl["infl_bytes"], pl["ring_index"], pl["ring_bytes"])
+            e.upload_term_range(np.zeros(G, dtype=np.uint64), pl["match"].max(axis=0) + np.uint64(16))
+            # record 16 + aux 8 + link 4+4 + action 1+1 + head 4+4 + the Progress read and written back
+            # (match, next, pending, infl bytes 8+8 each; state 1+1; infl meta 4+4) = 116
+            timed("k_progress_link + k_progress_apply, random cells (K9)", "event", N, 116,
+                  lambda: L.rafthip_step_progress(e._h, d_ev.data_ptr(), d_aux.data_ptr(), N, d_act.data_ptr()))
+        del pl, ev, aux, d_ev, d_aux, d_act
     # sorted-by-group stream (a host that buckets acks by range)
     order = np.argsort(recs["group"], kind="stable")
     d_recs = torch.from_numpy(np.ascontiguousarray(recs[order]).view(np.uint8)).to(dev)
