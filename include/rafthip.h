@@ -306,8 +306,9 @@ int rafthip_ingest_wire(rafthip_engine *e, const uint8_t *bytes, const uint64_t 
 /* Allocate the per-peer planes: Next, State, MsgAppFlowPaused, PendingSnapshot
  * and an Inflights ring of max_inflight entries per Progress (Config.MaxInflightMsgs,
  * raft.go:205-211; max_inflight_bytes = Config.MaxInflightBytes, 0 = no limit,
- * raft.go:212-220; tracker.NewInflights, tracker/inflights.go:46-51).  Device
- * memory: S * stride * (16 * max_inflight + 33) bytes.  Once per engine. */
+ * raft.go:212-220; tracker.NewInflights, tracker/inflights.go:46-51), at most
+ * 16383 entries.  Device memory: S * stride * (16 * max_inflight + 32) bytes.
+ * Once per engine. */
 int rafthip_progress_config(rafthip_engine *e, uint32_t max_inflight, uint64_t max_inflight_bytes);
 
 /* (Re)initialise Progress rows — what raft.reset (raft.go:774-784), becomeLeader

@@ -7,12 +7,12 @@
 // by an ack is not an ack followed by a rejection.  Events of one batch are
 // therefore applied in stream order per Progress, by exactly one lane:
 //
-//   k_progress_link   every event swaps its index into head[cell] (one 32-bit
-//                     atomic exchange) and keeps what it found in prev[i]: a
-//                     linked list per Progress, in whatever order the
-//                     exchanges ran.  Leader-log growth records (kMsgAppended)
+//   k_progress_link   every event swaps its index into its Progress record's
+//                     head word (one 32-bit atomic exchange) and keeps what it
+//                     found in prev[i]: a linked list per Progress, in whatever
+//                     order the exchanges ran.  Leader-log growth records (kMsgAppended)
 //                     are applied here, i.e. before every response.
-//   k_progress_apply  the event that still owns head[cell] (the last to
+//   k_progress_apply  the event that still owns the head word (the last to
 //                     exchange) walks the list, takes the events in ascending
 //                     stream index and steps them through the state machine
 //                     with the Progress in registers; plain loads / stores, no
@@ -50,13 +50,26 @@ enum : uint8_t {  // = RAFTHIP_ACT_*
     kActDropped = 128,
 };
 
+// Everything of a Progress but Match (which the commit kernels stream as a
+// plane) in ONE 32-byte record, so a step costs one line read and one line
+// write instead of six of each: the apply pass is bound by the number of
+// scattered lines it touches, not by bytes.  The list head of the link pass
+// lives in the same record.
+struct alignas(32) ProgRec {
+    u64 next;
+    u64 pending;  // PendingSnapshot
+    u64 ibytes;   // Inflights.bytes
+    u32 meta;     // Inflights.start (bits 0-13) | Inflights.count (14-28) | State (29-30) | MsgAppFlowPaused (31)
+    u32 head;     // k_progress_link / k_progress_apply; zero between calls
+};
+constexpr u32 kMaxInflight = 16383;
+__host__ __device__ __forceinline__ u32 rec_meta(u32 start, u32 count, u32 pstate) {
+    return start | (count << 14) | (pstate << 29);
+}
+
 struct ProgPlanes {
     u64* match;        // [S][stride]
-    u64* next;         // [S][stride]
-    uint8_t* pstate;   // [S][stride] bits 0-1 State, bit 2 MsgAppFlowPaused
-    u64* pending;      // [S][stride] PendingSnapshot
-    u32* infl_meta;    // [S][stride] start | count << 16
-    u64* infl_bytes;   // [S][stride]
+    ProgRec* rec;      // [S][stride]
     u64* ring_index;   // [cap][S][stride]
     u64* ring_bytes;   // [cap][S][stride]
     u64 stride;
@@ -102,7 +115,7 @@ __device__ __forceinline__ bool prog_is_paused(const Prog& p) {  // progress.go:
 }
 
 // Inflights.FreeLE, inflights.go:98-128, on the cell's ring in global memory.
-__device__ void infl_free_le(Prog& p, const ProgPlanes& pl, u64 cell, u64 to) {
+__device__ __forceinline__ void infl_free_le(Prog& p, const ProgPlanes& pl, u64 cell, u64 to) {
     if (p.icount == 0 || to < pl.ring_index[(u64)p.istart * pl.plane + cell]) return;
     u32 idx = p.istart, i = 0;
     u64 bytes = 0;
@@ -119,8 +132,8 @@ __device__ void infl_free_le(Prog& p, const ProgPlanes& pl, u64 cell, u64 to) {
 
 // One event on one Progress: stepLeader, raft.go:1333-1586, and the send-side
 // bookkeeping of maybeSendAppend, raft.go:645,653.  Returns the action byte.
-__device__ uint8_t prog_step(Prog& p, const ProgPlanes& pl, u64 cell, u32 type, bool reject, u32 flags, u64 index,
-                             u64 aux, u64 last_index, u64 first_index) {
+__device__ __forceinline__ uint8_t prog_step(Prog& p, const ProgPlanes& pl, u64 cell, u32 type, bool reject, u32 flags,
+                                             u64 index, u64 aux, const u64* last_index, const u64* first_index) {
     uint8_t act = 0;
     switch (type) {
         case kMsgAppResp:
@@ -154,7 +167,7 @@ __device__ uint8_t prog_step(Prog& p, const ProgPlanes& pl, u64 cell, u32 type, 
                 if (updated || (p.match == index && p.state == kStateProbe)) {  // :1477
                     if (p.state == kStateProbe) {
                         prog_become_replicate(p);
-                    } else if (p.state == kStateSnapshot && p.match + 1 >= first_index) {
+                    } else if (p.state == kStateSnapshot && p.match + 1 >= (first_index ? *first_index : 0)) {
                         prog_become_probe(p);
                         prog_become_replicate(p);
                     } else if (p.state == kStateReplicate) {
@@ -162,14 +175,14 @@ __device__ uint8_t prog_step(Prog& p, const ProgPlanes& pl, u64 cell, u32 type, 
                     }
                     act |= kActUpdated;
                     if (old_paused) act |= kActWasPaused;
-                    if (p.match == last_index) act |= kActCaughtUp;
+                    if (p.match == *last_index) act |= kActCaughtUp;
                 }
             }
             break;
         case kMsgHeartbeatResp:  // :1527-1561
             p.active = true;
             p.paused = 0;
-            if (p.match < last_index || p.state == kStateProbe) act |= kActSendAppend;
+            if (p.state == kStateProbe || p.match < *last_index) act |= kActSendAppend;
             if (flags & kMsgFlagCtx) p.read_ack = true;
             break;
         case kEvSnapStatus:  // :1562-1579
@@ -237,7 +250,7 @@ __device__ __forceinline__ MsgFields load_msg(const Msg* msgs, u64 i) {
 }
 
 __global__ __launch_bounds__(kBlock) void k_progress_link(const Msg* __restrict__ msgs, u32 n, u64 G, u32 S,
-                                                          u64 stride, u32* __restrict__ head,
+                                                          u64 stride, ProgRec* __restrict__ rec,
                                                           u32* __restrict__ prev, u64* __restrict__ term_last,
                                                           uint8_t* __restrict__ actions) {
     const u32 i = blockIdx.x * kBlock + threadIdx.x;
@@ -254,7 +267,7 @@ __global__ __launch_bounds__(kBlock) void k_progress_link(const Msg* __restrict_
     } else if (!prog_event_type(f.type) || (u64)f.group >= G || f.slot >= S) {
         act = kActDropped;
     } else {
-        prev[i] = atomicExch(head + (u64)f.slot * stride + f.group, i + 1);
+        prev[i] = atomicExch(&rec[(u64)f.slot * stride + f.group].head, i + 1);
         act = kActDeferred;
     }
     actions[i] = act;
@@ -262,10 +275,9 @@ __global__ __launch_bounds__(kBlock) void k_progress_link(const Msg* __restrict_
 
 __global__ __launch_bounds__(kBlock) void k_progress_apply(const Msg* __restrict__ msgs,
                                                            const u64* __restrict__ aux, u32 n, u64 G, u32 S,
-                                                           ProgPlanes pl, u32* __restrict__ head,
-                                                           const u32* __restrict__ prev, void* __restrict__ active,
-                                                           void* __restrict__ acks, int mbytes,
-                                                           const u64* __restrict__ term_last,
+                                                           ProgPlanes pl, const u32* __restrict__ prev,
+                                                           void* __restrict__ active, void* __restrict__ acks,
+                                                           int mbytes, const u64* __restrict__ term_last,
                                                            const u64* __restrict__ first_index,
                                                            uint8_t* __restrict__ actions) {
     const u32 i = blockIdx.x * kBlock + threadIdx.x;
@@ -273,27 +285,30 @@ __global__ __launch_bounds__(kBlock) void k_progress_apply(const Msg* __restrict
     const MsgFields own = load_msg(msgs, i);
     if (!prog_event_type(own.type) || (u64)own.group >= G || own.slot >= S) return;
     const u64 cell = (u64)own.slot * pl.stride + own.group;
-    if (head[cell] != i + 1) return;  // another event of this Progress exchanged later: it owns the list
+    u64* rw = reinterpret_cast<u64*>(pl.rec + cell);
+    const Vec<u64, 2> r0 = load_vec<u64, 2>(rw), r1 = load_vec<u64, 2>(rw + 2);
+    if ((u32)(r1.v[1] >> 32) != i + 1) return;  // another event of this Progress exchanged later: it owns the list
 
     u32 len = 0;
     for (u32 j = i + 1; j != 0 && len <= kStepLimit; j = prev[j - 1]) ++len;
     if (len > kStepLimit) {  // all of them stay DEFERRED
-        head[cell] = 0;
+        pl.rec[cell].head = 0;
         return;
     }
     Prog p;
-    p.match = pl.match[cell];
-    p.next = pl.next[cell];
-    p.pending = pl.pending[cell];
-    p.ibytes = pl.infl_bytes[cell];
-    const u32 ps = pl.pstate[cell], meta = pl.infl_meta[cell];
-    p.state = ps & 3u;
-    p.paused = (ps >> 2) & 1u;
-    p.istart = meta & 0xFFFFu;
-    p.icount = meta >> 16;
+    const u64 match0 = pl.match[cell];
+    const u32 meta = (u32)r1.v[1];
+    p.match = match0;
+    p.next = r0.v[0];
+    p.pending = r0.v[1];
+    p.ibytes = r1.v[0];
+    p.state = (meta >> 29) & 3u;
+    p.paused = meta >> 31;
+    p.istart = meta & 0x3FFFu;
+    p.icount = (meta >> 14) & 0x7FFFu;
     p.active = p.read_ack = false;
-    const u64 last_index = term_last[own.group];
-    const u64 first = first_index ? first_index[own.group] : 0;
+    const u64* last_index = term_last + own.group;
+    const u64* first = first_index ? first_index + own.group : nullptr;
 
     u32 done = 0;  // stream index + 1 of the last event stepped
     for (u32 k = 0; k < len; ++k) {
@@ -308,25 +323,69 @@ __global__ __launch_bounds__(kBlock) void k_progress_apply(const Msg* __restrict
                                      last_index, first);
         done = cur;
     }
-    pl.match[cell] = p.match;
-    pl.next[cell] = p.next;
-    pl.pending[cell] = p.pending;
-    pl.infl_bytes[cell] = p.ibytes;
-    pl.pstate[cell] = (uint8_t)(p.state | (p.paused << 2));
-    pl.infl_meta[cell] = p.istart | (p.icount << 16);
+    if (p.match != match0) pl.match[cell] = p.match;
+    Vec<u64, 2> w0, w1;
+    w0.v[0] = p.next;
+    w0.v[1] = p.pending;
+    w1.v[0] = p.ibytes;
+    w1.v[1] = (u64)rec_meta(p.istart, p.icount, p.state | (p.paused << 2));  // head = 0
+    store_vec<u64, 2>(rw, w0);
+    store_vec<u64, 2>(rw + 2, w1);
     if (p.active) or_slot_bit(active, mbytes, own.group, own.slot);
     if (p.read_ack) or_slot_bit(acks, mbytes, own.group, own.slot);
-    head[cell] = 0;
 }
 
-// Fresh Inflights for a range of groups (Progress upload = ResetState, progress.go:102-107).
-__global__ __launch_bounds__(kBlock) void k_progress_clear_inflights(u32* __restrict__ meta, u64* __restrict__ bytes,
-                                                                     u64 stride, u64 first, u64 count, u32 S) {
+// ---- SoA <-> record conversion for the upload / read entry points -----------
+// (the C ABI speaks [slot][group] planes like every other call)
+
+// (Re)initialise records of groups [first, first+count): State / paused / Next /
+// PendingSnapshot from planes of row pitch `count`, fresh Inflights
+// (Progress.ResetState, progress.go:102-107).
+__global__ __launch_bounds__(kBlock) void k_progress_pack(ProgRec* __restrict__ rec, u64 stride, u64 first, u64 count,
+                                                          u32 S, const uint8_t* __restrict__ pstate,
+                                                          const u64* __restrict__ next,
+                                                          const u64* __restrict__ pending) {
     const u64 g = (u64)blockIdx.x * kBlock + threadIdx.x;
     if (g >= count) return;
     for (u32 s = 0; s < S; ++s) {
-        meta[(u64)s * stride + first + g] = 0;
-        bytes[(u64)s * stride + first + g] = 0;
+        ProgRec r;
+        r.next = next[(u64)s * count + g];
+        r.pending = pending ? pending[(u64)s * count + g] : 0;
+        r.ibytes = 0;
+        r.meta = rec_meta(0, 0, pstate[(u64)s * count + g] & 7u);
+        r.head = 0;
+        rec[(u64)s * stride + first + g] = r;
+    }
+}
+
+// Inflights.start / count / bytes of a range from planes (meta = start | count << 16).
+__global__ __launch_bounds__(kBlock) void k_progress_set_inflights(ProgRec* __restrict__ rec, u64 stride, u64 first,
+                                                                   u64 count, u32 S, const u32* __restrict__ meta,
+                                                                   const u64* __restrict__ bytes) {
+    const u64 g = (u64)blockIdx.x * kBlock + threadIdx.x;
+    if (g >= count) return;
+    for (u32 s = 0; s < S; ++s) {
+        ProgRec& r = rec[(u64)s * stride + first + g];
+        const u32 m = meta[(u64)s * count + g];
+        r.meta = rec_meta(m & 0xFFFFu, m >> 16, r.meta >> 29);
+        r.ibytes = bytes[(u64)s * count + g];
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_progress_unpack(const ProgRec* __restrict__ rec, u64 stride, u64 first,
+                                                            u64 count, u32 S, uint8_t* __restrict__ pstate,
+                                                            u64* __restrict__ next, u64* __restrict__ pending,
+                                                            u32* __restrict__ meta, u64* __restrict__ bytes) {
+    const u64 g = (u64)blockIdx.x * kBlock + threadIdx.x;
+    if (g >= count) return;
+    for (u32 s = 0; s < S; ++s) {
+        const ProgRec r = rec[(u64)s * stride + first + g];
+        const u64 o = (u64)s * count + g;
+        pstate[o] = (uint8_t)(r.meta >> 29);
+        next[o] = r.next;
+        pending[o] = r.pending;
+        meta[o] = (r.meta & 0x3FFFu) | (((r.meta >> 14) & 0x7FFFu) << 16);
+        bytes[o] = r.ibytes;
     }
 }
 

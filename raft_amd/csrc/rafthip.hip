@@ -120,7 +120,6 @@ struct rafthip_engine {
     // per-peer replication state (rafthip_progress_config)
     bool prog = false;
     ProgPlanes pp{};
-    u32* prog_head = nullptr;   // [S][stride] list heads of rafthip_step_progress, zero between calls
     u64* first_index = nullptr; // raftLog.firstIndex() per group
 
     rafthip_stats_t stats{};
@@ -607,8 +606,7 @@ int rafthip_destroy(rafthip_engine* e) {
                     e->d_rejected, e->self_mask, e->term_first, e->term_last, e->hb_commit, e->in_term,
                     e->ids, e->cur_term, e->read_ctx, e->read_ctx_len, e->d_wire_counts,
                     e->wire_buf[0], e->wire_buf[1], e->wire_buf[2], e->wire_buf[3], e->wire_buf[4],
-                    e->wire_buf[5], e->wire_buf[6], e->wire_buf[7], e->pp.next, e->pp.pstate, e->pp.pending,
-                    e->pp.infl_meta, e->pp.infl_bytes, e->pp.ring_index, e->pp.ring_bytes, e->prog_head,
+                    e->wire_buf[5], e->wire_buf[6], e->wire_buf[7], e->pp.rec, e->pp.ring_index, e->pp.ring_bytes,
                     e->first_index};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
@@ -1001,7 +999,7 @@ static int need_progress(const rafthip_engine* e) {
 
 int rafthip_progress_config(rafthip_engine* e, uint32_t max_inflight, uint64_t max_inflight_bytes) {
     if (!e) return fail(RAFTHIP_EINVAL, "engine is NULL");
-    if (max_inflight > 65535) return fail(RAFTHIP_EINVAL, "max_inflight %u > 65535", max_inflight);
+    if (max_inflight > kMaxInflight) return fail(RAFTHIP_EINVAL, "max_inflight %u > %u", max_inflight, kMaxInflight);
     if (e->prog) {
         if (e->pp.cap == max_inflight && e->pp.max_bytes == max_inflight_bytes) return RAFTHIP_OK;
         return fail(RAFTHIP_EINVAL, "the Inflights limits of an engine are fixed once configured");
@@ -1010,14 +1008,9 @@ int rafthip_progress_config(rafthip_engine* e, uint32_t max_inflight, uint64_t m
     const size_t cells = (size_t)e->S * e->stride;
     const size_t ring = (size_t)(max_inflight ? max_inflight : 1) * cells * sizeof(u64);
     int rc;
-    if ((rc = ensure(e, e->pp.next, cells * sizeof(u64)))) return rc;
-    if ((rc = ensure(e, e->pp.pstate, cells))) return rc;
-    if ((rc = ensure(e, e->pp.pending, cells * sizeof(u64)))) return rc;
-    if ((rc = ensure(e, e->pp.infl_meta, cells * sizeof(u32)))) return rc;
-    if ((rc = ensure(e, e->pp.infl_bytes, cells * sizeof(u64)))) return rc;
+    if ((rc = ensure(e, e->pp.rec, cells * sizeof(ProgRec)))) return rc;
     if ((rc = ensure(e, e->pp.ring_index, ring))) return rc;
     if ((rc = ensure(e, e->pp.ring_bytes, ring))) return rc;
-    if ((rc = ensure(e, e->prog_head, cells * sizeof(u32)))) return rc;
     if ((rc = ensure(e, e->first_index, (size_t)e->stride * sizeof(u64)))) return rc;
     if ((rc = ensure(e, e->term_last, (size_t)e->stride * sizeof(u64)))) return rc;
     if ((rc = ensure(e, e->term_first, (size_t)e->stride * sizeof(u64)))) return rc;
@@ -1030,6 +1023,24 @@ int rafthip_progress_config(rafthip_engine* e, uint32_t max_inflight, uint64_t m
     return RAFTHIP_OK;
 }
 
+namespace {
+
+// Transient [S][count] planes on the device for the SoA <-> record conversions.
+struct TempPlanes {
+    char* base = nullptr;
+    ~TempPlanes() {
+        if (base) (void)hipFree(base);
+    }
+    int alloc(size_t bytes) {
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&base), bytes));
+        return RAFTHIP_OK;
+    }
+};
+
+size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+}  // namespace
+
 int rafthip_upload_progress(rafthip_engine* e, uint64_t first, uint64_t count, const uint8_t* state,
                             const uint64_t* next, const uint64_t* pending, uint64_t src_stride) {
     int rc = need_progress(e);
@@ -1038,19 +1049,22 @@ int rafthip_upload_progress(rafthip_engine* e, uint64_t first, uint64_t count, c
     if (src_stride < count) return fail(RAFTHIP_EINVAL, "src_stride %llu < count %llu", (u64)src_stride, (u64)count);
     if (count == 0) return RAFTHIP_OK;
     DeviceGuard guard(e->device);
-    const u64 st = e->stride;
-    if ((rc = copy_rows(e, e->pp.pstate + first, st, state, src_stride, count, e->S))) return rc;
-    if ((rc = copy_rows(e, e->pp.next + first, st * 8, next, src_stride * 8, count * 8, e->S))) return rc;
-    if (pending) {
-        if ((rc = copy_rows(e, e->pp.pending + first, st * 8, pending, src_stride * 8, count * 8, e->S))) return rc;
-    } else {
-        HIP_TRY(hipMemset2DAsync(e->pp.pending + first, st * 8, 0, count * 8, e->S, e->stream));
-    }
-    hipLaunchKernelGGL(k_progress_clear_inflights, dim3((u32)((count + kBlock - 1) / kBlock)), dim3(kBlock), 0,
-                       e->stream, e->pp.infl_meta, e->pp.infl_bytes, st, (u64)first, (u64)count, e->S);
+    const size_t cells = (size_t)e->S * count;
+    const size_t o_next = align256(cells), o_pend = o_next + cells * 8;
+    TempPlanes t;
+    if ((rc = t.alloc(o_pend + cells * 8))) return rc;
+    uint8_t* t_state = reinterpret_cast<uint8_t*>(t.base);
+    u64* t_next = reinterpret_cast<u64*>(t.base + o_next);
+    u64* t_pend = reinterpret_cast<u64*>(t.base + o_pend);
+    if ((rc = copy_rows(e, t_state, count, state, src_stride, count, e->S))) return rc;
+    if ((rc = copy_rows(e, t_next, count * 8, next, src_stride * 8, count * 8, e->S))) return rc;
+    if (pending && (rc = copy_rows(e, t_pend, count * 8, pending, src_stride * 8, count * 8, e->S))) return rc;
+    hipLaunchKernelGGL(k_progress_pack, dim3((u32)((count + kBlock - 1) / kBlock)), dim3(kBlock), 0, e->stream,
+                       e->pp.rec, e->stride, (u64)first, (u64)count, e->S, static_cast<const uint8_t*>(t_state),
+                       static_cast<const u64*>(t_next), pending ? static_cast<const u64*>(t_pend) : nullptr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(e->stream));
-    e->stats.bytes_uploaded += count * e->S * (pending ? 17 : 9);
+    e->stats.bytes_uploaded += cells * (pending ? 17 : 9);
     return RAFTHIP_OK;
 }
 
@@ -1059,20 +1073,30 @@ int rafthip_read_progress(rafthip_engine* e, uint64_t first, uint64_t count, uin
     int rc = need_progress(e);
     if (rc || (rc = check_range(e, first, count))) return rc;
     if (dst_stride < count) return fail(RAFTHIP_EINVAL, "dst_stride %llu < count %llu", (u64)dst_stride, (u64)count);
+    if (count == 0) return RAFTHIP_OK;
     DeviceGuard guard(e->device);
-    const u64 st = e->stride;
-    if (state && (rc = copy_rows(e, state, dst_stride, e->pp.pstate + first, st, count, e->S))) return rc;
-    if (next && (rc = copy_rows(e, next, dst_stride * 8, e->pp.next + first, st * 8, count * 8, e->S))) return rc;
-    if (pending && (rc = copy_rows(e, pending, dst_stride * 8, e->pp.pending + first, st * 8, count * 8, e->S)))
-        return rc;
-    if (infl_meta && (rc = copy_rows(e, infl_meta, dst_stride * 4, e->pp.infl_meta + first, st * 4, count * 4, e->S)))
-        return rc;
-    if (infl_bytes &&
-        (rc = copy_rows(e, infl_bytes, dst_stride * 8, e->pp.infl_bytes + first, st * 8, count * 8, e->S)))
-        return rc;
+    const size_t cells = (size_t)e->S * count;
+    const size_t o_next = align256(cells), o_pend = o_next + cells * 8, o_bytes = o_pend + cells * 8,
+                 o_meta = o_bytes + cells * 8;
+    TempPlanes t;
+    if ((rc = t.alloc(o_meta + cells * 4))) return rc;
+    uint8_t* t_state = reinterpret_cast<uint8_t*>(t.base);
+    u64* t_next = reinterpret_cast<u64*>(t.base + o_next);
+    u64* t_pend = reinterpret_cast<u64*>(t.base + o_pend);
+    u64* t_bytes = reinterpret_cast<u64*>(t.base + o_bytes);
+    u32* t_meta = reinterpret_cast<u32*>(t.base + o_meta);
+    hipLaunchKernelGGL(k_progress_unpack, dim3((u32)((count + kBlock - 1) / kBlock)), dim3(kBlock), 0, e->stream,
+                       static_cast<const ProgRec*>(e->pp.rec), e->stride, (u64)first, (u64)count, e->S, t_state,
+                       t_next, t_pend, t_meta, t_bytes);
+    HIP_TRY(hipGetLastError());
+    if (state && (rc = copy_rows(e, state, dst_stride, t_state, count, count, e->S))) return rc;
+    if (next && (rc = copy_rows(e, next, dst_stride * 8, t_next, count * 8, count * 8, e->S))) return rc;
+    if (pending && (rc = copy_rows(e, pending, dst_stride * 8, t_pend, count * 8, count * 8, e->S))) return rc;
+    if (infl_meta && (rc = copy_rows(e, infl_meta, dst_stride * 4, t_meta, count * 4, count * 4, e->S))) return rc;
+    if (infl_bytes && (rc = copy_rows(e, infl_bytes, dst_stride * 8, t_bytes, count * 8, count * 8, e->S))) return rc;
     HIP_TRY(hipStreamSynchronize(e->stream));
-    e->stats.bytes_downloaded += count * e->S * ((state ? 1 : 0) + (next ? 8 : 0) + (pending ? 8 : 0) +
-                                                 (infl_meta ? 4 : 0) + (infl_bytes ? 8 : 0));
+    e->stats.bytes_downloaded += cells * ((state ? 1 : 0) + (next ? 8 : 0) + (pending ? 8 : 0) +
+                                          (infl_meta ? 4 : 0) + (infl_bytes ? 8 : 0));
     return RAFTHIP_OK;
 }
 
@@ -1083,10 +1107,20 @@ int rafthip_upload_inflights(rafthip_engine* e, uint64_t first, uint64_t count, 
     if (rc || (rc = check_range(e, first, count))) return rc;
     if (!infl_meta || !infl_bytes || !ring_index || !ring_bytes) return fail(RAFTHIP_EINVAL, "a source is NULL");
     if (src_stride < count) return fail(RAFTHIP_EINVAL, "src_stride %llu < count %llu", (u64)src_stride, (u64)count);
+    if (count == 0) return RAFTHIP_OK;
     DeviceGuard guard(e->device);
     const u64 st = e->stride, rows = (u64)(e->pp.cap ? e->pp.cap : 1) * e->S;
-    if ((rc = copy_rows(e, e->pp.infl_meta + first, st * 4, infl_meta, src_stride * 4, count * 4, e->S))) return rc;
-    if ((rc = copy_rows(e, e->pp.infl_bytes + first, st * 8, infl_bytes, src_stride * 8, count * 8, e->S))) return rc;
+    const size_t cells = (size_t)e->S * count;
+    TempPlanes t;
+    if ((rc = t.alloc(cells * 12))) return rc;
+    u64* t_bytes = reinterpret_cast<u64*>(t.base);
+    u32* t_meta = reinterpret_cast<u32*>(t.base + cells * 8);
+    if ((rc = copy_rows(e, t_meta, count * 4, infl_meta, src_stride * 4, count * 4, e->S))) return rc;
+    if ((rc = copy_rows(e, t_bytes, count * 8, infl_bytes, src_stride * 8, count * 8, e->S))) return rc;
+    hipLaunchKernelGGL(k_progress_set_inflights, dim3((u32)((count + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                       e->stream, e->pp.rec, st, (u64)first, (u64)count, e->S, static_cast<const u32*>(t_meta),
+                       static_cast<const u64*>(t_bytes));
+    HIP_TRY(hipGetLastError());
     if ((rc = copy_rows(e, e->pp.ring_index + first, st * 8, ring_index, src_stride * 8, count * 8, rows))) return rc;
     if ((rc = copy_rows(e, e->pp.ring_bytes + first, st * 8, ring_bytes, src_stride * 8, count * 8, rows))) return rc;
     HIP_TRY(hipStreamSynchronize(e->stream));
@@ -1148,11 +1182,11 @@ int rafthip_step_progress(rafthip_engine* e, const rafthip_msg* msgs, const uint
     u32* prev = static_cast<u32*>(e->wire_buf[7]);
     const u32 blocks = (u32)((n + kBlock - 1) / kBlock);
     hipLaunchKernelGGL(k_progress_link, dim3(blocks), dim3(kBlock), 0, e->stream, static_cast<const Msg*>(d_recs),
-                       (u32)n, e->G, e->S, e->stride, e->prog_head, prev, e->term_last, d_act);
+                       (u32)n, e->G, e->S, e->stride, e->pp.rec, prev, e->term_last, d_act);
     HIP_TRY(hipGetLastError());
     e->pp.match = e->match;
     hipLaunchKernelGGL(k_progress_apply, dim3(blocks), dim3(kBlock), 0, e->stream, static_cast<const Msg*>(d_recs),
-                       static_cast<const u64*>(d_aux), (u32)n, e->G, e->S, e->pp, e->prog_head,
+                       static_cast<const u64*>(d_aux), (u32)n, e->G, e->S, e->pp,
                        static_cast<const u32*>(prev), e->active, e->acks, e->mbytes,
                        static_cast<const u64*>(e->term_last), static_cast<const u64*>(e->first_index), d_act);
     HIP_TRY(hipGetLastError());
