@@ -108,10 +108,8 @@ struct rafthip_engine {
     u64* h_scalar = nullptr;    // pinned, 4 x u64
 
     // wire ingest
-    u64* ids = nullptr;            // [G][S] raft id per Progress row, 0 = empty
-    u64* cur_term = nullptr;       // r.Term per group
-    u64* read_ctx = nullptr;       // pending ReadIndex context (<= 8 bytes, little-endian) ...
-    uint8_t* read_ctx_len = nullptr;  // ... and its length, 0 = none
+    u64* wire_hdr = nullptr;       // [G][H] per group: r.Term, pending ReadIndex ctx, its length, raft id per slot (wire.h)
+    bool have_ids = false, have_term = false;
     u64* d_wire_counts = nullptr;  // [RAFTHIP_WIRE_STATUSES]
     // growable staging: wire bytes, offsets, groups, out msgs, out status; progress aux, actions, prev links
     void* wire_buf[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -604,7 +602,7 @@ int rafthip_destroy(rafthip_engine* e) {
                     e->active,  e->acks,       e->vote_result,  e->granted,  e->rejected, e->qactive,
                     e->ack_result, e->stage,   e->packed,       e->counts,   e->offsets,  e->ack_buf,
                     e->d_rejected, e->self_mask, e->term_first, e->term_last, e->hb_commit, e->in_term,
-                    e->ids, e->cur_term, e->read_ctx, e->read_ctx_len, e->d_wire_counts,
+                    e->wire_hdr, e->d_wire_counts,
                     e->wire_buf[0], e->wire_buf[1], e->wire_buf[2], e->wire_buf[3], e->wire_buf[4],
                     e->wire_buf[5], e->wire_buf[6], e->wire_buf[7], e->pp.rec, e->pp.ring_index, e->pp.ring_bytes,
                     e->first_index};
@@ -842,6 +840,42 @@ int rafthip_ingest_msgs(rafthip_engine* e, const rafthip_msg* msgs, uint64_t n) 
 
 // ---- wire ingest -----------------------------------------------------------
 
+namespace {
+
+int ensure_wire_hdr(rafthip_engine* e) {
+    return ensure(e, e->wire_hdr, (size_t)e->G * wire_hdr_words(e->S) * sizeof(u64));
+}
+
+// `bytes` of host or device memory as a device pointer valid until *tmp is freed.
+int device_view(rafthip_engine* e, const void* src, size_t bytes, void** tmp, const void** dev) {
+    *tmp = nullptr;
+    if (is_device_ptr(src)) {
+        *dev = src;
+        return RAFTHIP_OK;
+    }
+    HIP_TRY(hipMalloc(tmp, bytes));
+    hipError_t err = hipMemcpyAsync(*tmp, src, bytes, hipMemcpyHostToDevice, e->stream);
+    if (err != hipSuccess) {
+        (void)hipFree(*tmp);
+        *tmp = nullptr;
+        HIP_TRY(err);
+    }
+    *dev = *tmp;
+    return RAFTHIP_OK;
+}
+
+int finish_and_free(rafthip_engine* e, void* a, void* b) {
+    const hipError_t err = hipGetLastError();
+    const hipError_t err2 = hipStreamSynchronize(e->stream);
+    if (a) (void)hipFree(a);
+    if (b) (void)hipFree(b);
+    HIP_TRY(err);
+    HIP_TRY(err2);
+    return RAFTHIP_OK;
+}
+
+}  // namespace
+
 int rafthip_upload_ids(rafthip_engine* e, uint64_t first, uint64_t count, const uint64_t* ids,
                        uint64_t src_stride) {
     int rc = check_range(e, first, count);
@@ -849,20 +883,20 @@ int rafthip_upload_ids(rafthip_engine* e, uint64_t first, uint64_t count, const 
     if (!ids) return fail(RAFTHIP_EINVAL, "ids is NULL");
     if (src_stride < count) return fail(RAFTHIP_EINVAL, "src_stride %llu < count %llu", (u64)src_stride, (u64)count);
     DeviceGuard guard(e->device);
-    if ((rc = ensure(e, e->ids, (size_t)e->G * e->S * sizeof(u64)))) return rc;
+    if ((rc = ensure_wire_hdr(e))) return rc;
+    e->have_ids = true;
     if (count == 0) return RAFTHIP_OK;
+    const u32 H = wire_hdr_words(e->S);
     void* tmp = nullptr;
     HIP_TRY(hipMalloc(&tmp, (size_t)count * e->S * sizeof(u64)));
     hipError_t err = hipMemcpy2DAsync(tmp, count * 8, ids, src_stride * 8, count * 8, e->S, hipMemcpyDefault, e->stream);
-    if (err == hipSuccess) {
-        hipLaunchKernelGGL(k_ids_to_rows, dim3((u32)((count + kBlock - 1) / kBlock)), dim3(kBlock), 0, e->stream,
-                           static_cast<const u64*>(tmp), (u64)count, e->S, e->ids + first * e->S);
-        err = hipGetLastError();
+    if (err != hipSuccess) {
+        (void)hipFree(tmp);
+        HIP_TRY(err);
     }
-    const hipError_t err2 = hipStreamSynchronize(e->stream);
-    (void)hipFree(tmp);
-    HIP_TRY(err);
-    HIP_TRY(err2);
+    hipLaunchKernelGGL(k_hdr_set_ids, dim3((u32)((count + kBlock - 1) / kBlock)), dim3(kBlock), 0, e->stream,
+                       static_cast<const u64*>(tmp), (u64)count, e->S, H, e->wire_hdr + first * H);
+    if ((rc = finish_and_free(e, tmp, nullptr))) return rc;
     e->stats.bytes_uploaded += count * 8 * e->S;
     return RAFTHIP_OK;
 }
@@ -872,9 +906,17 @@ int rafthip_upload_term(rafthip_engine* e, uint64_t first, uint64_t count, const
     if (rc) return rc;
     if (!term) return fail(RAFTHIP_EINVAL, "term is NULL");
     DeviceGuard guard(e->device);
-    if ((rc = ensure(e, e->cur_term, (size_t)e->stride * sizeof(u64)))) return rc;
-    HIP_TRY(hipMemcpyAsync(e->cur_term + first, term, count * 8, hipMemcpyDefault, e->stream));
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    if ((rc = ensure_wire_hdr(e))) return rc;
+    e->have_term = true;
+    if (count == 0) return RAFTHIP_OK;
+    const u32 H = wire_hdr_words(e->S);
+    void* tmp = nullptr;
+    const void* d_term = nullptr;
+    if ((rc = device_view(e, term, count * 8, &tmp, &d_term))) return rc;
+    hipLaunchKernelGGL(k_hdr_set_field, dim3((u32)((count + kBlock - 1) / kBlock)), dim3(kBlock), 0, e->stream,
+                       static_cast<const u64*>(d_term), static_cast<const uint8_t*>(nullptr), (u64)count, H, kHdrTerm,
+                       0u, e->wire_hdr + first * H);
+    if ((rc = finish_and_free(e, tmp, nullptr))) return rc;
     e->stats.bytes_uploaded += count * 8;
     return RAFTHIP_OK;
 }
@@ -885,11 +927,20 @@ int rafthip_upload_read_ctx(rafthip_engine* e, uint64_t first, uint64_t count, c
     if (rc) return rc;
     if (!ctx || !ctx_len) return fail(RAFTHIP_EINVAL, "ctx/ctx_len is NULL");
     DeviceGuard guard(e->device);
-    if ((rc = ensure(e, e->read_ctx, (size_t)e->stride * sizeof(u64)))) return rc;
-    if ((rc = ensure(e, e->read_ctx_len, (size_t)e->stride))) return rc;
-    HIP_TRY(hipMemcpyAsync(e->read_ctx + first, ctx, count * 8, hipMemcpyDefault, e->stream));
-    HIP_TRY(hipMemcpyAsync(e->read_ctx_len + first, ctx_len, count, hipMemcpyDefault, e->stream));
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    if ((rc = ensure_wire_hdr(e))) return rc;
+    if (count == 0) return RAFTHIP_OK;
+    const u32 H = wire_hdr_words(e->S);
+    void *tmp = nullptr, *tmp8 = nullptr;
+    const void *d_ctx = nullptr, *d_len = nullptr;
+    if ((rc = device_view(e, ctx, count * 8, &tmp, &d_ctx))) return rc;
+    if ((rc = device_view(e, ctx_len, count, &tmp8, &d_len))) {
+        if (tmp) (void)hipFree(tmp);
+        return rc;
+    }
+    hipLaunchKernelGGL(k_hdr_set_field, dim3((u32)((count + kBlock - 1) / kBlock)), dim3(kBlock), 0, e->stream,
+                       static_cast<const u64*>(d_ctx), static_cast<const uint8_t*>(d_len), (u64)count, H, kHdrCtx,
+                       kHdrCtxLen, e->wire_hdr + first * H);
+    if ((rc = finish_and_free(e, tmp, tmp8))) return rc;
     e->stats.bytes_uploaded += count * 9;
     return RAFTHIP_OK;
 }
@@ -900,15 +951,13 @@ int rafthip_ingest_wire(rafthip_engine* e, const uint8_t* bytes, const uint64_t*
     if (status_counts) memset(status_counts, 0, RAFTHIP_WIRE_STATUSES * sizeof(uint64_t));
     if (n == 0) return RAFTHIP_OK;
     if (!offsets || !groups) return fail(RAFTHIP_EINVAL, "offsets/groups is NULL");
-    if (!e->ids || !e->cur_term)
+    if (!e->have_ids || !e->have_term)
         return fail(RAFTHIP_EINVAL, "rafthip_upload_ids and rafthip_upload_term must come first");
     DeviceGuard guard(e->device);
     int rc;
     const size_t mb = (size_t)e->stride * e->mbytes;
     if ((rc = ensure(e, e->active, mb))) return rc;
     if ((rc = ensure(e, e->acks, mb))) return rc;
-    if ((rc = ensure(e, e->read_ctx, (size_t)e->stride * sizeof(u64)))) return rc;
-    if ((rc = ensure(e, e->read_ctx_len, (size_t)e->stride))) return rc;
     if ((rc = ensure(e, e->d_wire_counts, RAFTHIP_WIRE_STATUSES * sizeof(u64)))) return rc;
 
     // total byte length = offsets[n] (the kernel bounds every message by it)
@@ -953,8 +1002,8 @@ int rafthip_ingest_wire(rafthip_engine* e, const uint8_t* bytes, const uint64_t*
         const u32 blocks = (u32)((m + kWireBlock - 1) / kWireBlock);
         hipLaunchKernelGGL(k_ingest_wire, dim3(blocks), dim3(kWireBlock), 0, e->stream,
                            static_cast<const uint8_t*>(d_bytes), nbytes, static_cast<const u64*>(d_off) + off,
-                           static_cast<const u32*>(d_groups) + off, m, e->G, e->S, e->ids, e->cur_term, e->read_ctx,
-                           e->read_ctx_len, e->match, e->stride, e->active, e->acks, e->mbytes,
+                           static_cast<const u32*>(d_groups) + off, m, e->G, e->S, static_cast<const u64*>(e->wire_hdr),
+                           wire_hdr_words(e->S), e->match, e->stride, e->active, e->acks, e->mbytes,
                            d_msgs ? d_msgs + off : nullptr, d_status ? d_status + off : nullptr, e->d_wire_counts);
         HIP_TRY(hipGetLastError());
     }

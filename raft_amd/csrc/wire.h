@@ -160,11 +160,17 @@ __device__ bool wire_parse(const R& rd, i64 pos, i64 end, WireFields& f) {
     return true;
 }
 
+// The per-group lookup state of the wire path as ONE row per group, H = 3 + S
+// rounded up to 4 words (32-byte aligned rows): [term][ctx][ctx_len][ids...].
+// A decoded message gathers its term, its sender's slot and the pending
+// ReadIndex context from one or two lines instead of five.
+constexpr u32 kHdrTerm = 0, kHdrCtx = 1, kHdrCtxLen = 2, kHdrIds = 3;
+__host__ __device__ __forceinline__ u32 wire_hdr_words(u32 S) { return (kHdrIds + S + 3u) & ~3u; }
+
 __global__ __launch_bounds__(kWireBlock) void k_ingest_wire(
     const uint8_t* __restrict__ bytes, u64 nbytes, const u64* __restrict__ offsets,
-    const u32* __restrict__ groups, u64 n, u64 G, u32 S, const u64* __restrict__ ids /* [G][S] */,
-    const u64* __restrict__ cur_term, const u64* __restrict__ read_ctx,
-    const uint8_t* __restrict__ read_ctx_len, u64* __restrict__ match, u64 stride,
+    const u32* __restrict__ groups, u64 n, u64 G, u32 S, const u64* __restrict__ hdr /* [G][H] */, u32 H,
+    u64* __restrict__ match, u64 stride,
     void* __restrict__ active, void* __restrict__ acks, int mbytes, Msg* __restrict__ out_msgs,
     uint8_t* __restrict__ out_status, u64* __restrict__ counters /* [kWireStatuses] */) {
     __shared__ __align__(16) uint8_t sm[kWireLdsBytes + 32];
@@ -224,16 +230,16 @@ __global__ __launch_bounds__(kWireBlock) void k_ingest_wire(
             } else if (f.nested) {
                 status = kWireNested;
             } else {
-                const u64 term = cur_term[group];
+                const u64* row = hdr + (u64)group * H;  // one or two lines hold all the group's lookup state
+                const u64 term = row[kHdrTerm];
                 if (f.term != 0 && f.term > term) {
                     status = kWireHigherTerm;
                 } else if (f.term != 0 && f.term < term) {
                     status = kWireStaleTerm;
                 } else {
-                    const u64* row = ids + (u64)group * S;
                     if (f.from != 0) {
                         for (u32 s = 0; s < S; ++s) {
-                            if (row[s] == f.from) {
+                            if (row[kHdrIds + s] == f.from) {
                                 slot = s;
                                 break;
                             }
@@ -246,8 +252,8 @@ __global__ __launch_bounds__(kWireBlock) void k_ingest_wire(
                         if (app) {
                             if (!f.reject) atomicMax(match + (u64)slot * stride + group, f.index);  // :1477
                         } else {
-                            const u32 want = read_ctx_len[group];
-                            if (want != 0 && f.ctx_len == want && f.ctx == read_ctx[group]) {
+                            const u64 want = row[kHdrCtxLen];
+                            if (want != 0 && f.ctx_len == want && f.ctx == row[kHdrCtx]) {
                                 flags |= kMsgFlagCtx;
                                 or_slot_bit(acks, mbytes, group, slot);  // read_only.go:68-76
                             }
@@ -271,13 +277,21 @@ __global__ __launch_bounds__(kWireBlock) void k_ingest_wire(
     if (threadIdx.x < kWireStatuses && hist[threadIdx.x] != 0) atomicAdd(counters + threadIdx.x, (u64)hist[threadIdx.x]);
 }
 
-// Id table upload: [S][count] planes (the layout every other upload uses) ->
-// group-major rows, so one lookup reads one contiguous run of S ids.
-__global__ __launch_bounds__(kBlock) void k_ids_to_rows(const u64* __restrict__ src, u64 count, u32 S,
-                                                        u64* __restrict__ dst) {
+// ids [S][count] planes (the layout every other upload uses) -> the rows.
+__global__ __launch_bounds__(kBlock) void k_hdr_set_ids(const u64* __restrict__ src, u64 count, u32 S, u32 H,
+                                                        u64* __restrict__ hdr /* row of the first group */) {
     const u64 g = (u64)blockIdx.x * kBlock + threadIdx.x;
     if (g >= count) return;
-    for (u32 s = 0; s < S; ++s) dst[g * S + s] = src[(u64)s * count + g];
+    for (u32 s = 0; s < S; ++s) hdr[g * H + kHdrIds + s] = src[(u64)s * count + g];
+}
+// One word (and optionally a byte-wide second field) per group -> its row.
+__global__ __launch_bounds__(kBlock) void k_hdr_set_field(const u64* __restrict__ src, const uint8_t* __restrict__ src8,
+                                                          u64 count, u32 H, u32 field, u32 field8,
+                                                          u64* __restrict__ hdr) {
+    const u64 g = (u64)blockIdx.x * kBlock + threadIdx.x;
+    if (g >= count) return;
+    hdr[g * H + field] = src[g];
+    if (src8) hdr[g * H + field8] = src8[g];
 }
 
 }  // namespace rafthip

@@ -240,9 +240,9 @@ def main():
             e.upload_progress(pl["pstate"], pl["next"], pl["pending"])
             e.upload_inflights(pl["infl_meta"], pl["infl_bytes"], pl["ring_index"], pl["ring_bytes"])
             e.upload_term_range(np.zeros(G, dtype=np.uint64), pl["match"].max(axis=0) + np.uint64(16))
-            # record 16 + aux 8 + link 4+4 + action 1+1 + head 4+4 + the Progress read and written back
-            # (match, next, pending, infl bytes 8+8 each; state 1+1; infl meta 4+4) = 116
-            timed("k_progress_link + k_progress_apply, random cells (K9)", "event", N, 116,
+            # record 16 + aux 8 + link 4+4 + action 1+1 + the 32-byte Progress record read and written
+            # back + Match read (written only when it moves) = 106
+            timed("k_progress_link + k_progress_apply, random cells (K9)", "event", N, 106,
                   lambda: L.rafthip_step_progress(e._h, d_ev.data_ptr(), d_aux.data_ptr(), N, d_act.data_ptr()))
         del pl, ev, aux, d_ev, d_aux, d_act
     # sorted-by-group stream (a host that buckets acks by range)
