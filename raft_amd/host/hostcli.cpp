@@ -18,6 +18,10 @@
 //   leader <g> <self> <term_first> <last_index> | follower <g> | setcommitted <g> <c>
 //   appended <g> <last_index> | step <g> <from> <type> <index> <reject 0|1> <ctx 0|1>
 //   maybecommit | checkquorum | hbcommit <g> <id>
+//   progress <max_inflight> <max_bytes> | firstindex <g> <i>
+//   initprogress <g> <default_next> rows=<id>:<state>:<match>:<next>:<pending>:<paused>,...
+//   ev <g> <peer> <type> <index> <reject 0|1> <flag 0|1> <aux>     queued
+//   flushprogress  -> "actions a0,a1,..." | progressof <g> <id>
 // Any failure prints "error <code> <text>" and processing continues.
 #include <inttypes.h>
 #include <stdio.h>
@@ -215,6 +219,36 @@ int main() {
                     for (uint8_t x : a) putchar('0' + x);
                     printf("\n");
                 }
+            } else if (cmd == "progress") {
+                rc = trk->EnableProgress((uint32_t)u(1), u(2));
+            } else if (cmd == "firstindex") {
+                rc = trk->SetFirstIndex(u(1), u(2));
+            } else if (cmd == "initprogress") {
+                std::map<uint64_t, tracker::BatchProgressTracker::ProgressInit> rows;
+                for (const auto& r : split(arg(t, "rows"), ',')) {
+                    const auto f = split(r, ':');
+                    if (f.size() != 6) continue;
+                    auto n = [&](size_t i) { return strtoull(f[i].c_str(), nullptr, 10); };
+                    rows[n(0)] = {(int)n(1), n(2), n(3), n(4), n(5) != 0};
+                }
+                rc = trk->InitProgress(u(1), rows, u(2));
+            } else if (cmd == "ev") {
+                if (!trk->StepEvent(u(1), u(2), (int)u(3), u(4), u(5) != 0, u(6) != 0, u(7))) printf("dropped\n");
+            } else if (cmd == "flushprogress") {
+                std::vector<uint8_t> a;
+                if (!(rc = trk->FlushProgress(&a))) {
+                    printf("actions");
+                    for (size_t i = 0; i < a.size(); ++i) printf("%c%u", i ? ',' : ' ', (unsigned)a[i]);
+                    printf("\n");
+                }
+            } else if (cmd == "progressof") {
+                tracker::BatchProgressTracker::ProgressView v;
+                if (!(rc = trk->ProgressOf(u(1), u(2), &v)))
+                    printf("progressof %" PRIu64 " %" PRIu64 " state=%d match=%" PRIu64 " next=%" PRIu64 " pending=%" PRIu64
+                           " paused=%d is_paused=%d active=%d inflight=%u bytes=%" PRIu64 " full=%d\n",
+                           u(1), u(2), v.state, v.match, v.next, v.pending_snapshot, (int)v.msg_app_flow_paused,
+                           (int)v.is_paused, (int)v.recent_active, v.inflight_count, v.inflight_bytes,
+                           (int)v.inflight_full);
             } else if (cmd == "hbcommit") {
                 uint64_t c = 0;
                 if (!(rc = trk->HeartbeatCommit(u(1), u(2), &c)))

@@ -224,6 +224,7 @@ int BatchProgressTracker::Flush() {
         if (rc) return rc;
     }
     if (!msgs_.empty()) {
+        if (progress_) return FlushProgress(nullptr);
         rc = lib(rafthip_ingest_msgs(e_, msgs_.data(), msgs_.size()));
         msgs_.clear();
     }
@@ -431,6 +432,7 @@ bool BatchProgressTracker::Appended(uint64_t group, uint64_t last_index) {
     m.type = RAFTHIP_MSG_APPENDED;
     m.index = last_index;
     msgs_.push_back(m);
+    if (progress_) aux_.push_back(0);
     return true;
 }
 
@@ -457,6 +459,7 @@ bool BatchProgressTracker::Step(uint64_t group, uint64_t from, int type, uint64_
     m.flags = read_ctx ? RAFTHIP_MSGF_READ_CTX : 0;
     m.index = index;
     msgs_.push_back(m);
+    if (progress_) aux_.push_back(0);
     return true;
 }
 
@@ -506,6 +509,120 @@ int BatchProgressTracker::HeartbeatCommit(uint64_t group, uint64_t id, uint64_t*
     std::vector<uint64_t> row(S_, 0);
     if ((rc = lib(rafthip_heartbeat_commit(e_, group, 1, row.data(), 1)))) return rc;
     *commit = row[s];
+    return RAFTHIP_OK;
+}
+
+// ---- per-peer replication state ------------------------------------------------
+
+int BatchProgressTracker::EnableProgress(uint32_t max_inflight, uint64_t max_inflight_bytes) {
+    int rc = Flush();
+    if (rc) return rc;
+    if ((rc = lib(rafthip_progress_config(e_, max_inflight, max_inflight_bytes)))) return rc;
+    progress_ = true;
+    max_inflight_ = max_inflight;
+    max_inflight_bytes_ = max_inflight_bytes;
+    return RAFTHIP_OK;
+}
+
+int BatchProgressTracker::InitProgress(uint64_t group, const std::map<uint64_t, ProgressInit>& rows,
+                                       uint64_t default_next) {
+    if (group >= G_) return fail(RAFTHIP_ERANGE, "group %llu outside [0, %llu)", (unsigned long long)group,
+                                 (unsigned long long)G_);
+    if (!progress_) return fail(RAFTHIP_EINVAL, "EnableProgress must come first");
+    int rc = Flush();
+    if (rc) return rc;
+    std::vector<uint8_t> state(S_, RAFTHIP_STATE_PROBE);
+    std::vector<uint64_t> match(S_, 0), next(S_, default_next), pending(S_, 0);
+    for (const auto& kv : rows) {
+        const int s = slot_of(group, kv.first);
+        if (s < 0) return fail(RAFTHIP_EINVAL, "group %llu has no Progress for id %llu", (unsigned long long)group,
+                               (unsigned long long)kv.first);
+        state[s] = (uint8_t)(kv.second.state | (kv.second.msg_app_flow_paused ? RAFTHIP_PROGRESS_PAUSED : 0));
+        match[s] = kv.second.match;
+        next[s] = kv.second.next;
+        pending[s] = kv.second.pending_snapshot;
+    }
+    if ((rc = lib(rafthip_upload_match(e_, group, 1, match.data(), 1)))) return rc;
+    return lib(rafthip_upload_progress(e_, group, 1, state.data(), next.data(), pending.data(), 1));
+}
+
+int BatchProgressTracker::SetFirstIndex(uint64_t group, uint64_t first_index) {
+    int rc = Flush();
+    if (rc) return rc;
+    return lib(rafthip_upload_first_index(e_, group, 1, &first_index));
+}
+
+bool BatchProgressTracker::StepEvent(uint64_t group, uint64_t peer, int type, uint64_t index, bool reject, bool flag,
+                                     uint64_t aux) {
+    if (group >= G_ || !progress_) return false;
+    const int s = slot_of(group, peer);
+    if (s < 0) return false;
+    if (type == RAFTHIP_MSG_APP_RESP || type == RAFTHIP_MSG_HEARTBEAT_RESP) {  // the shadowed bit planes follow
+        put_mask(active_, group, get_mask(active_, group) | (1ull << s));
+        touch(active_dirty_, group);
+        if (type == RAFTHIP_MSG_HEARTBEAT_RESP && flag) {
+            put_mask(rdacks_, group, get_mask(rdacks_, group) | (1ull << s));
+            touch(rdacks_dirty_, group);
+        }
+    }
+    rafthip_msg m;
+    memset(&m, 0, sizeof(m));
+    m.group = (uint32_t)group;
+    m.slot = (uint8_t)s;
+    m.type = (uint8_t)type;
+    m.reject = reject ? 1 : 0;
+    m.flags = flag ? 1 : 0;  // RAFTHIP_MSGF_READ_CTX / "carried entries"
+    m.index = index;
+    msgs_.push_back(m);
+    aux_.push_back(aux);
+    return true;
+}
+
+int BatchProgressTracker::FlushProgress(std::vector<uint8_t>* actions) {
+    if (!progress_) return fail(RAFTHIP_EINVAL, "EnableProgress must come first");
+    int rc = RAFTHIP_OK;
+    if (!acks_.empty()) {
+        rc = lib(rafthip_scatter_acks(e_, acks_.data(), acks_.size()));
+        acks_.clear();
+        if (rc) return rc;
+    }
+    if (actions) actions->assign(msgs_.size(), 0);
+    if (!msgs_.empty()) {
+        rc = lib(rafthip_step_progress(e_, msgs_.data(), aux_.data(), msgs_.size(), actions ? actions->data() : nullptr));
+        msgs_.clear();
+        aux_.clear();
+    }
+    return rc;
+}
+
+int BatchProgressTracker::ProgressOf(uint64_t group, uint64_t id, ProgressView* out) {
+    if (!out) return fail(RAFTHIP_EINVAL, "out is NULL");
+    if (group >= G_) return fail(RAFTHIP_ERANGE, "group %llu outside [0, %llu)", (unsigned long long)group,
+                                 (unsigned long long)G_);
+    if (!progress_) return fail(RAFTHIP_EINVAL, "EnableProgress must come first");
+    const int s = slot_of(group, id);
+    if (s < 0) return fail(RAFTHIP_EINVAL, "group %llu has no Progress for id %llu", (unsigned long long)group,
+                           (unsigned long long)id);
+    int rc = Flush();
+    if (rc) return rc;
+    std::vector<uint8_t> state(S_, 0);
+    std::vector<uint64_t> match(S_, 0), next(S_, 0), pending(S_, 0), ibytes(S_, 0);
+    std::vector<uint32_t> meta(S_, 0);
+    if ((rc = lib(rafthip_read_match(e_, group, 1, match.data(), 1)))) return rc;
+    if ((rc = lib(rafthip_read_progress(e_, group, 1, state.data(), next.data(), pending.data(), meta.data(),
+                                        ibytes.data(), 1))))
+        return rc;
+    out->state = state[s] & 3;
+    out->msg_app_flow_paused = (state[s] & RAFTHIP_PROGRESS_PAUSED) != 0;
+    out->is_paused = out->state == RAFTHIP_STATE_SNAPSHOT ? true : out->msg_app_flow_paused;
+    out->match = match[s];
+    out->next = next[s];
+    out->pending_snapshot = pending[s];
+    out->recent_active = ((get_mask(active_, group) >> s) & 1) != 0;
+    out->inflight_count = meta[s] >> 16;
+    out->inflight_bytes = ibytes[s];
+    out->inflight_full = out->inflight_count == max_inflight_ ||
+                         (max_inflight_bytes_ != 0 && ibytes[s] >= max_inflight_bytes_);
     return RAFTHIP_OK;
 }
 

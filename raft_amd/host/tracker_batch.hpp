@@ -114,6 +114,44 @@ class BatchProgressTracker {
     // sendHeartbeat's commit for peer `id` (raft.go:669-685), after MaybeCommit().
     int HeartbeatCommit(uint64_t group, uint64_t id, uint64_t* commit);
 
+    // ---- per-peer replication state: tracker.Progress + tracker.Inflights ----------
+    // (tracker/progress.go:30-98, tracker/inflights.go:28-40)
+
+    // The limits tracker.MakeProgressTracker takes (tracker/tracker.go:129-145):
+    // Config.MaxInflightMsgs / MaxInflightBytes.  From here on Step/StepEvent run
+    // the whole stepLeader branch (Probe/Replicate/Snapshot, Next, Inflights).
+    int EnableProgress(uint32_t max_inflight, uint64_t max_inflight_bytes);
+    struct ProgressInit {
+        int state;  // RAFTHIP_STATE_*
+        uint64_t match, next, pending_snapshot;
+        bool msg_app_flow_paused;
+    };
+    // Every Progress of the group at once, as raft.reset / becomeLeader /
+    // a conf change leave them (raft.go:774-784,915-920); ids without an entry
+    // get the reset value {StateProbe, Match 0, Next `default_next`}.  Inflights
+    // start empty.
+    int InitProgress(uint64_t group, const std::map<uint64_t, ProgressInit>& rows, uint64_t default_next);
+    int SetFirstIndex(uint64_t group, uint64_t first_index);  // raftLog.firstIndex()
+    // One event for the Progress of `peer`, queued: type is a raftpb.MessageType
+    // (MsgAppResp 4, MsgHeartbeatResp 9, MsgUnreachable 10, MsgSnapStatus 11) or
+    // RAFTHIP_MSG_SENT_APP / RAFTHIP_MSG_SENT_SNAP; flag = read_ctx for a heartbeat
+    // response, "carried entries" for SENT_APP; aux = nextProbeIdx of a rejection,
+    // payload bytes of SENT_APP.  Returns false when the group has no Progress
+    // for peer (raft.go:1327-1331).
+    bool StepEvent(uint64_t group, uint64_t peer, int type, uint64_t index, bool reject, bool flag, uint64_t aux);
+    // Steps everything queued, in order; *actions gets one RAFTHIP_ACT_* byte set
+    // per StepEvent / Step / Appended call since the last flush.
+    int FlushProgress(std::vector<uint8_t>* actions);
+    struct ProgressView {
+        int state;
+        uint64_t match, next, pending_snapshot;
+        bool msg_app_flow_paused, recent_active, is_paused;  // IsPaused(), progress.go:225-236
+        uint32_t inflight_count;
+        uint64_t inflight_bytes;
+        bool inflight_full;  // Inflights.Full(), inflights.go:131-133
+    };
+    int ProgressOf(uint64_t group, uint64_t id, ProgressView* out);
+
     rafthip_engine* engine() { return e_; }
 
    private:
@@ -135,7 +173,11 @@ class BatchProgressTracker {
     std::vector<uint64_t> used_;     // [G] slots that hold a Progress
     std::vector<uint8_t> in_, out_, learner_;  // [G] masks, mb_ bytes each
     std::vector<rafthip_ack> acks_;  // queued MaybeUpdate calls
-    std::vector<rafthip_msg> msgs_;  // queued Step / Appended calls
+    std::vector<rafthip_msg> msgs_;  // queued Step / StepEvent / Appended calls
+    std::vector<uint64_t> aux_;      // one per queued msg once EnableProgress ran
+    bool progress_ = false;
+    uint32_t max_inflight_ = 0;
+    uint64_t max_inflight_bytes_ = 0;
     std::vector<uint8_t> self_;      // [G] masks: the leader's own slot
     uint64_t self_dirty_[2] = {1, 0};
     std::vector<CommitPair> pairs_;  // landing buffer of Committed(), G entries

@@ -381,3 +381,52 @@ def test_tracker_leader_tick(oracle, S, G, seed):
         assert a == b, (k, a, b)
     assert len(out) == len(want)
     assert any(l.startswith("advanced") for l in want)
+
+
+@pytest.mark.gpu
+def test_tracker_progress_scenarios():
+    """The reference's Progress / Inflights scenarios (tests/golden/progress.json) through
+    the C++ mirror: peer 2 of a three-voter group, one flush per event and the state /
+    action the reference's tests state after each; then the same events in one flush."""
+    import progress_util as pu
+    from oracle import pyoracle as po
+
+    fx = pu.load_fixture()
+    ev_type = pu.EV
+    for sc in fx["scenarios"]:
+        steps = pu.scenario_steps(sc)
+        init = sc["init"]
+        head = ["tracker 4 3", "setconfig 2 in=1,2,3 out= learners=", "progress %d %d" % (sc["cap"], sc["max_bytes"]),
+                "leader 2 1 1 %d" % sc["last_index"], "firstindex 2 %d" % sc["first_index"],
+                "initprogress 2 1 rows=2:%d:%d:%d:%d:%d" % (po.STATE_NAMES[init["state"]], init["match"], init["next"],
+                                                              init.get("pending", 0), int(bool(init.get("paused"))))]
+
+        def ev_line(st):
+            if st["ev"] == "appended":
+                return "appended 2 %d" % st["index"]
+            flag = int(bool(st.get("entries"))) if st["ev"] == "sent_app" else 0
+            aux = st.get("bytes", 0) if st["ev"] == "sent_app" else st.get("hint", 0)
+            return "ev 2 2 %d %d %d %d %d" % (ev_type[st["ev"]], st.get("index", 0), int(bool(st.get("reject"))), flag, aux)
+
+        script = list(head)
+        for st in steps:
+            script += [ev_line(st), "flushprogress", "progressof 2 2"]
+        one_batch = len(steps) <= po.STEP_LIMIT and not any(st["ev"] == "appended" for st in steps)
+        if one_batch:
+            script += head[2 + 1:]  # re-initialise the same tracker: leader, firstindex, initprogress
+            script += [ev_line(st) for st in steps] + ["flushprogress", "progressof 2 2"]
+        out = run_cli("\n".join(script) + "\n")
+        assert not [l for l in out if l.startswith("error") or l == "dropped"], out[:5]
+        acts = [l for l in out if l.startswith("actions")]
+        views = [dict(kv.split("=") for kv in l.split()[3:]) for l in out if l.startswith("progressof")]
+        assert len(acts) == len(views) == len(steps) + (1 if one_batch else 0)
+        for i, st in enumerate(steps):
+            got = {k: int(v) for k, v in views[i].items()}
+            got["is_paused"], got["paused"], got["full"] = bool(got["is_paused"]), bool(got["paused"]), bool(got["full"])
+            pu.check_expect(st, got, (sc["src"], i))
+            pu.check_actions(st, int(acts[i].split()[1]) if len(acts[i].split()) > 1 else 0, (sc["src"], i))
+            if st["ev"] in ("app_resp", "heartbeat_resp"):
+                assert got["active"] == 1
+        if one_batch:
+            assert views[-1] == views[len(steps) - 1], sc["src"]
+            assert len(acts[-1].split()[1].split(",")) == len(steps)
