@@ -254,7 +254,11 @@ int rafthip_upload_read_ctx(rafthip_engine *e, uint64_t first, uint64_t count, c
                                       decodes it; not applied */
 #define RAFTHIP_WIRE_MALFORMED 6   /* Message.Unmarshal returns an error (raftpb/raft.pb.go:1801-2179) */
 #define RAFTHIP_WIRE_BAD_GROUP 7   /* envelope group id >= num_groups */
-#define RAFTHIP_WIRE_STATUSES 8
+#define RAFTHIP_WIRE_NEEDS_LOG 8   /* rafthip_step_wire only: a rejection with LogTerm > 0, whose next probe index needs
+                                      findConflictByTerm on the leader's log (raft.go:1458): the host steps it */
+#define RAFTHIP_WIRE_STATUSES 9
+#define RAFTHIP_MSG_NEEDS_HOST 0xFE /* record type of such a message: it and every later event of the same Progress
+                                       in the batch come back RAFTHIP_ACT_DEFERRED, so stream order per Progress holds */
 #define RAFTHIP_MSGF_HAS_CTX 2     /* out record flag: Message.Context is non-empty */
 #define RAFTHIP_WIRE_NO_SLOT 0xFF  /* out record slot / type when unresolved / outside uint8 */
 
@@ -356,6 +360,19 @@ int rafthip_upload_first_index(rafthip_engine *e, uint64_t first, uint64_t count
  * device memory.  Requires rafthip_progress_config.  n <= 2^31. */
 int rafthip_step_progress(rafthip_engine *e, const rafthip_msg *msgs, const uint64_t *aux, uint64_t n,
                           uint8_t *actions);
+
+/* rafthip_ingest_wire's decode and classification feeding rafthip_step_progress
+ * instead of the max / or updates: serialized responses in, Progress transitions
+ * and action bytes out, no host pass in between.  A message with status
+ * RAFTHIP_WIRE_APPLIED is stepped (a rejection with LogTerm 0 probes at
+ * m.RejectHint, raft.go:1362); RAFTHIP_WIRE_NEEDS_LOG is left to the host (which
+ * steps it with rafthip_step_progress once it has the hint, then resubmits the
+ * DEFERRED events of that Progress, order kept); every other status is not an
+ * event (RAFTHIP_ACT_DROPPED).  Requires rafthip_progress_config, rafthip_upload_ids
+ * and rafthip_upload_term.  status_counts has RAFTHIP_WIRE_STATUSES entries. */
+int rafthip_step_wire(rafthip_engine *e, const uint8_t *bytes, const uint64_t *offsets,
+                      const uint32_t *groups, uint64_t n, rafthip_msg *out_msgs, uint8_t *out_status,
+                      uint64_t *status_counts, uint8_t *actions);
 
 /* ProgressTracker.Committed for every group — tracker/tracker.go:179-181 =
  * JointConfig.CommittedIndex (quorum/joint.go:49-56) over

@@ -246,6 +246,9 @@ enum {
     EV_APPENDED = 0xF0,  /* the leader's log grew to `index` (appendEntry, raft.go:791-819) */
     EV_SENT_APP = 0xF1,  /* a MsgApp went out: UpdateOnEntriesSend (raft.go:653) */
     EV_SENT_SNAP = 0xF2, /* a MsgSnap went out: BecomeSnapshot(index) (raft.go:645) */
+    EV_NEEDS_HOST = 0xFE, /* a response only the host can step (a rejection whose hint needs the leader's
+                             log, raft.go:1458): it and every later event of the same Progress in the
+                             batch are left unstepped (ACT_DEFERRED), so stream order per Progress holds */
 };
 /* what the reference does next with the message, left to the host */
 enum {
@@ -371,7 +374,8 @@ ORACLE_API void oracle_step_progress(uint64_t G, int nslots, uint64_t stride, ui
             continue;
         }
         const int known = m->type == EV_APP_RESP || m->type == EV_HEARTBEAT_RESP || m->type == EV_UNREACHABLE ||
-                          m->type == EV_SNAP_STATUS || m->type == EV_SENT_APP || m->type == EV_SENT_SNAP;
+                          m->type == EV_SNAP_STATUS || m->type == EV_SENT_APP || m->type == EV_SENT_SNAP ||
+                          m->type == EV_NEEDS_HOST;
         if (!known || m->group >= G || m->slot >= nslots) {
             actions[i] = ACT_DROPPED;
             continue;
@@ -386,6 +390,8 @@ ORACLE_API void oracle_step_progress(uint64_t G, int nslots, uint64_t stride, ui
         if (actions[i] != ACT_DEFERRED) continue;
         const uint64_t cell = (uint64_t)m->slot * stride + m->group;
         if (cnt[cell] > limit) continue;
+        if (m->type == EV_NEEDS_HOST) cnt[cell] = 0xFFFFFFFFu; /* blocks the rest of this Progress's events */
+        if (cnt[cell] == 0xFFFFFFFFu) continue;
         progress pr;
         pr.match = match[cell];
         pr.next = next[cell];

@@ -104,6 +104,9 @@ def lib():
         L.oracle_step_progress.restype = None
         L.oracle_step_progress.argtypes = [C.c_uint64, C.c_int, C.c_uint64] + [vp] * 8 + [C.c_int, C.c_uint64, vp, vp,
                                            C.c_int, vp, vp, vp, vp, C.c_uint64, C.c_uint32, vp]
+        L.oracle_decode_wire_msgs.restype = None
+        L.oracle_decode_wire_msgs.argtypes = [C.c_uint64, C.c_int, vp, C.c_uint64, vp, vp, vp, vp, C.c_uint64, vp, vp,
+                                              C.c_uint64, vp, vp, vp, vp]
         L.oracle_batch_check_quorum.restype = None
         L.oracle_batch_check_quorum.argtypes = [C.c_uint64, C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp]
         L.oracle_batch_heartbeat_commit.restype = None
@@ -355,6 +358,26 @@ def step_wire_msgs(match, active, acks, ids, term, read_ctx, read_ctx_len, data,
     return out_msgs, out_status, counts
 
 
+def decode_wire_msgs(ids, term, read_ctx, read_ctx_len, data, offsets, groups):
+    """Decode + classify only: (records, aux = RejectHint of rejections, status, counts[9]).  A rejection
+    with LogTerm > 0 is status 8 and record type 0xFE (the host steps it)."""
+    ids = _chk(ids, np.uint64)
+    S, G = ids.shape
+    offsets = _chk(np.ascontiguousarray(offsets), np.uint64)
+    groups = _chk(np.ascontiguousarray(groups), np.uint32)
+    n = len(groups)
+    data = _chk(np.ascontiguousarray(data), np.uint8)
+    out_msgs = np.zeros(n, dtype=MSG_DTYPE)
+    aux = np.zeros(n, dtype=np.uint64)
+    status = np.zeros(n, dtype=np.uint8)
+    counts = np.zeros(9, dtype=np.uint64)
+    lib().oracle_decode_wire_msgs(G, S, _vp(ids), ids.strides[0] // 8, _vp(_chk(term, np.uint64)),
+                                  _vp(_chk(read_ctx, np.uint64)), _vp(_chk(read_ctx_len, np.uint8)),
+                                  _vp(data) if len(data) else None, len(data), _vp(offsets), _vp(groups), n,
+                                  _vp(out_msgs), _vp(aux), _vp(status), _vp(counts))
+    return out_msgs, aux, status, counts
+
+
 def batch_check_quorum(active, nslots, self_mask, in_mask=None, out_mask=None, learner_mask=None,
                        uniform_voters=0):
     """MsgCheckQuorum for every group: returns QuorumActive u8; mutates active (all but self cleared)."""
@@ -420,7 +443,7 @@ class CpuBaseline:
 STATE_PROBE, STATE_REPLICATE, STATE_SNAPSHOT = 0, 1, 2
 STATE_NAMES = {"StateProbe": 0, "StateReplicate": 1, "StateSnapshot": 2}
 EV_APP_RESP, EV_HEARTBEAT_RESP, EV_UNREACHABLE, EV_SNAP_STATUS = 4, 9, 10, 11
-EV_APPENDED, EV_SENT_APP, EV_SENT_SNAP = 0xF0, 0xF1, 0xF2
+EV_APPENDED, EV_SENT_APP, EV_SENT_SNAP, EV_NEEDS_HOST = 0xF0, 0xF1, 0xF2, 0xFE
 ACT_SEND_APPEND, ACT_UPDATED, ACT_WAS_PAUSED, ACT_CAUGHT_UP, ACT_ERROR, ACT_DEFERRED, ACT_DROPPED = 1, 2, 4, 8, 32, 64, 128
 STEP_LIMIT = 64  # events per Progress per batch the engine steps (more: deferred)
 

@@ -827,18 +827,19 @@ ORACLE_API int oracle_message_unmarshal(const uint8_t *d, uint64_t l, oracle_pbm
  *   read_only.go:68-76).
  * ids is the ProgressMap key of each slot, [nslots][ids_stride], 0 = no row.
  */
-ORACLE_API void oracle_step_wire_msgs(uint64_t G, int nslots, uint64_t *match, uint64_t stride,
-                                      void *active, void *acks, int mask_bytes, const uint64_t *ids,
-                                      uint64_t ids_stride, const uint64_t *term,
-                                      const uint64_t *read_ctx, const uint8_t *read_ctx_len,
-                                      const uint8_t *bytes, uint64_t nbytes, const uint64_t *offsets,
-                                      const uint32_t *groups, uint64_t n, oracle_msg *out_msgs,
-                                      uint8_t *out_status, uint64_t *counts) {
-    for (int k = 0; k < 8; k++) counts[k] = 0;
+static void wire_msgs(int apply, uint64_t G, int nslots, uint64_t *match, uint64_t stride,
+                      void *active, void *acks, int mask_bytes, const uint64_t *ids,
+                      uint64_t ids_stride, const uint64_t *term,
+                      const uint64_t *read_ctx, const uint8_t *read_ctx_len,
+                      const uint8_t *bytes, uint64_t nbytes, const uint64_t *offsets,
+                      const uint32_t *groups, uint64_t n, oracle_msg *out_msgs, uint64_t *out_aux,
+                      uint8_t *out_status, uint64_t *counts) {
+    for (int k = 0; k < 9; k++) counts[k] = 0;
     for (uint64_t i = 0; i < n; i++) {
         oracle_msg o = {groups[i], 0xFF, 0xFF, 0, 0, 0};
         oracle_pbmsg m;
         int st, decoded = 0;
+        uint64_t aux = 0;
         uint64_t g = groups[i];
         if (g >= G) {
             st = 7;
@@ -869,9 +870,20 @@ ORACLE_API void oracle_step_wire_msgs(uint64_t G, int nslots, uint64_t *match, u
                 } else {
                     st = 0;
                     o.slot = (uint8_t)slot;
-                    store_mask(active, mask_bytes, g, load_mask(active, mask_bytes, g) | (1ULL << slot));
+                    if (apply) store_mask(active, mask_bytes, g, load_mask(active, mask_bytes, g) | (1ULL << slot));
                     if (m.type == 4) {
-                        if (!m.reject) {
+                        if (!apply) {
+                            /* decode for the Progress stepper: a rejection's nextProbeIdx is RejectHint
+                             * unless LogTerm > 0 asks for findConflictByTerm on the leader's log
+                             * (raft.go:1362-1459) — then the host steps it: status 8, record type 0xFE */
+                            if (m.reject) {
+                                aux = m.reject_hint;
+                                if (m.log_term > 0) {
+                                    st = 8;
+                                    o.type = 0xFE;
+                                }
+                            }
+                        } else if (!m.reject) {
                             uint64_t next = 0;
                             oracle_maybe_update(&match[(uint64_t)slot * stride + g], &next, m.index);
                         }
@@ -883,7 +895,7 @@ ORACLE_API void oracle_step_wire_msgs(uint64_t G, int nslots, uint64_t *match, u
                             if (bytes[offsets[i] + m.ctx_off + b] != (uint8_t)(want >> (8 * b))) same = 0;
                         if (same) {
                             o.flags |= 1;
-                            store_mask(acks, mask_bytes, g, load_mask(acks, mask_bytes, g) | (1ULL << slot));
+                            if (apply) store_mask(acks, mask_bytes, g, load_mask(acks, mask_bytes, g) | (1ULL << slot));
                         }
                     }
                 }
@@ -892,8 +904,34 @@ ORACLE_API void oracle_step_wire_msgs(uint64_t G, int nslots, uint64_t *match, u
         (void)decoded;
         counts[st]++;
         if (out_msgs) out_msgs[i] = o;
+        if (out_aux) out_aux[i] = aux;
         if (out_status) out_status[i] = (uint8_t)st;
     }
+}
+
+ORACLE_API void oracle_step_wire_msgs(uint64_t G, int nslots, uint64_t *match, uint64_t stride,
+                                      void *active, void *acks, int mask_bytes, const uint64_t *ids,
+                                      uint64_t ids_stride, const uint64_t *term,
+                                      const uint64_t *read_ctx, const uint8_t *read_ctx_len,
+                                      const uint8_t *bytes, uint64_t nbytes, const uint64_t *offsets,
+                                      const uint32_t *groups, uint64_t n, oracle_msg *out_msgs,
+                                      uint8_t *out_status, uint64_t *counts) {
+    uint64_t c9[9];
+    wire_msgs(1, G, nslots, match, stride, active, acks, mask_bytes, ids, ids_stride, term, read_ctx, read_ctx_len,
+              bytes, nbytes, offsets, groups, n, out_msgs, NULL, out_status, c9);
+    for (int k = 0; k < 8; k++) counts[k] = c9[k];
+}
+
+/* The same decode and classification without stepping anything: the records (and, for
+ * rejections, RejectHint as aux) that go on to the Progress stepper (oracle_step_progress). */
+ORACLE_API void oracle_decode_wire_msgs(uint64_t G, int nslots, const uint64_t *ids, uint64_t ids_stride,
+                                        const uint64_t *term, const uint64_t *read_ctx,
+                                        const uint8_t *read_ctx_len, const uint8_t *bytes, uint64_t nbytes,
+                                        const uint64_t *offsets, const uint32_t *groups, uint64_t n,
+                                        oracle_msg *out_msgs, uint64_t *out_aux, uint8_t *out_status,
+                                        uint64_t *counts /* [9] */) {
+    wire_msgs(0, G, nslots, NULL, 0, NULL, NULL, 1, ids, ids_stride, term, read_ctx, read_ctx_len, bytes, nbytes,
+              offsets, groups, n, out_msgs, out_aux, out_status, counts);
 }
 
 /*

@@ -41,7 +41,7 @@ SYMBOLS = [
     "rafthip_committed_in_term", "rafthip_read_committed_in_term",
     "rafthip_upload_ids", "rafthip_upload_term", "rafthip_upload_read_ctx", "rafthip_ingest_wire",
     "rafthip_progress_config", "rafthip_upload_progress", "rafthip_read_progress", "rafthip_upload_inflights",
-    "rafthip_read_inflights", "rafthip_upload_first_index", "rafthip_step_progress",
+    "rafthip_read_inflights", "rafthip_upload_first_index", "rafthip_step_progress", "rafthip_step_wire",
 ]
 
 STATE_PROBE, STATE_REPLICATE, STATE_SNAPSHOT, PROGRESS_PAUSED = 0, 1, 2, 4
@@ -50,9 +50,10 @@ ACT_SEND_APPEND, ACT_UPDATED, ACT_WAS_PAUSED, ACT_CAUGHT_UP, ACT_ERROR, ACT_DEFE
 STEP_LIMIT = 64
 
 
-WIRE_STATUSES = 8
+WIRE_STATUSES = 9
 (WIRE_APPLIED, WIRE_OTHER_TYPE, WIRE_NO_PROGRESS, WIRE_STALE_TERM, WIRE_HIGHER_TERM, WIRE_NESTED, WIRE_MALFORMED,
- WIRE_BAD_GROUP) = range(8)
+ WIRE_BAD_GROUP, WIRE_NEEDS_LOG) = range(9)
+MSG_NEEDS_HOST = 0xFE
 MSGF_READ_CTX, MSGF_HAS_CTX = 1, 2
 
 
@@ -163,6 +164,7 @@ def load_library():
         "rafthip_read_inflights": (i32, [vp, u64, u64, vp, vp, u64]),
         "rafthip_upload_first_index": (i32, [vp, u64, u64, vp]),
         "rafthip_step_progress": (i32, [vp, vp, vp, u64, vp]),
+        "rafthip_step_wire": (i32, [vp, vp, vp, vp, u64, vp, vp, vp, vp]),
     }
     assert sorted(sig) == sorted(SYMBOLS)
     for name, (res, args) in sig.items():
@@ -398,6 +400,18 @@ class Engine:
         actions = np.zeros(n, dtype=np.uint8) if want_actions else None
         _check(self._L.rafthip_step_progress(self._h, _ptr(msgs), _ptr(aux), n, _ptr(actions)))
         return actions
+
+    def step_wire(self, data, offsets, groups, n=None):
+        """Serialized messages -> (decoded records, status, counts[9], action bytes) through the Progress stepper."""
+        if n is None:
+            n = len(groups)
+        msgs = np.zeros(n, dtype=MSG_DTYPE)
+        status = np.zeros(n, dtype=np.uint8)
+        counts = np.zeros(WIRE_STATUSES, dtype=np.uint64)
+        actions = np.zeros(n, dtype=np.uint8)
+        _check(self._L.rafthip_step_wire(self._h, _ptr(data), _ptr(offsets), _ptr(groups), n, _ptr(msgs), _ptr(status),
+                                         _ptr(counts), _ptr(actions)))
+        return msgs, status, counts, actions
 
     def heartbeat_commit(self, first=0, count=None, download=True):
         first, count = self._range(first, count)

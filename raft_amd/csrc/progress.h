@@ -39,6 +39,7 @@ enum : uint8_t {  // raftpb/raft.proto:41-69 + the local records
     kEvSnapStatus = 11,
     kEvSentApp = 0xF1,
     kEvSentSnap = 0xF2,
+    kEvNeedsHostRec = 0xFE,  // = kEvNeedsHost of wire.h: a response only the host can step
 };
 enum : uint8_t {  // = RAFTHIP_ACT_*
     kActSendAppend = 1,
@@ -229,7 +230,7 @@ __device__ __forceinline__ uint8_t prog_step(Prog& p, const ProgPlanes& pl, u64 
 
 __device__ __forceinline__ bool prog_event_type(u32 type) {
     return type == kMsgAppResp || type == kMsgHeartbeatResp || type == kEvUnreachable || type == kEvSnapStatus ||
-           type == kEvSentApp || type == kEvSentSnap;
+           type == kEvSentApp || type == kEvSentSnap || type == kEvNeedsHostRec;
 }
 
 struct MsgFields {
@@ -311,6 +312,7 @@ __global__ __launch_bounds__(kBlock) void k_progress_apply(const Msg* __restrict
     const u64* first = first_index ? first_index + own.group : nullptr;
 
     u32 done = 0;  // stream index + 1 of the last event stepped
+    bool blocked = false;  // a host-only event was met: it and what follows it on this Progress stay DEFERRED
     for (u32 k = 0; k < len; ++k) {
         u32 cur = i + 1;
         if (len > 1) {  // the smallest index above `done`: lists are short, a re-walk beats a sort
@@ -319,8 +321,10 @@ __global__ __launch_bounds__(kBlock) void k_progress_apply(const Msg* __restrict
                 if (j > done && j < cur) cur = j;
         }
         const MsgFields f = cur == i + 1 ? own : load_msg(msgs, cur - 1);
-        actions[cur - 1] = prog_step(p, pl, cell, f.type, f.reject, f.flags, f.index, aux ? aux[cur - 1] : 0,
-                                     last_index, first);
+        blocked = blocked || f.type == kEvNeedsHostRec;
+        if (!blocked)
+            actions[cur - 1] = prog_step(p, pl, cell, f.type, f.reject, f.flags, f.index, aux ? aux[cur - 1] : 0,
+                                         last_index, first);
         done = cur;
     }
     if (p.match != match0) pl.match[cell] = p.match;

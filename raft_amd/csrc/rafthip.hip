@@ -22,6 +22,7 @@ static_assert(kWireApplied == RAFTHIP_WIRE_APPLIED && kWireOtherType == RAFTHIP_
                   kWireNoProgress == RAFTHIP_WIRE_NO_PROGRESS && kWireStaleTerm == RAFTHIP_WIRE_STALE_TERM &&
                   kWireHigherTerm == RAFTHIP_WIRE_HIGHER_TERM && kWireNested == RAFTHIP_WIRE_NESTED &&
                   kWireMalformed == RAFTHIP_WIRE_MALFORMED && kWireBadGroup == RAFTHIP_WIRE_BAD_GROUP &&
+                  kWireNeedsLog == RAFTHIP_WIRE_NEEDS_LOG && kEvNeedsHost == RAFTHIP_MSG_NEEDS_HOST &&
                   kWireStatuses == RAFTHIP_WIRE_STATUSES && kMsgFlagHasCtx == RAFTHIP_MSGF_HAS_CTX &&
                   kWireNoSlot == RAFTHIP_WIRE_NO_SLOT,
               "wire constants");
@@ -945,9 +946,17 @@ int rafthip_upload_read_ctx(rafthip_engine* e, uint64_t first, uint64_t count, c
     return RAFTHIP_OK;
 }
 
-int rafthip_ingest_wire(rafthip_engine* e, const uint8_t* bytes, const uint64_t* offsets, const uint32_t* groups,
-                        uint64_t n, rafthip_msg* out_msgs, uint8_t* out_status, uint64_t* status_counts) {
+static int progress_passes(rafthip_engine* e, const Msg* d_msgs, const u64* d_aux, uint64_t n, uint8_t* d_act);
+
+// Decode + classify n serialized messages; actions == NULL: step them as K7 does
+// (rafthip_ingest_wire); else hand the decoded records to the Progress stepper
+// (rafthip_step_wire).
+static int wire_run(rafthip_engine* e, const uint8_t* bytes, const uint64_t* offsets, const uint32_t* groups,
+                    uint64_t n, rafthip_msg* out_msgs, uint8_t* out_status, uint64_t* status_counts, bool to_progress,
+                    uint8_t* actions) {
     if (!e) return fail(RAFTHIP_EINVAL, "engine is NULL");
+    if (to_progress && !e->prog) return fail(RAFTHIP_EINVAL, "rafthip_progress_config must come first");
+    if (to_progress && n > (1ull << 31)) return fail(RAFTHIP_EINVAL, "more than 2^31 events in one batch: split it");
     if (status_counts) memset(status_counts, 0, RAFTHIP_WIRE_STATUSES * sizeof(uint64_t));
     if (n == 0) return RAFTHIP_OK;
     if (!offsets || !groups) return fail(RAFTHIP_EINVAL, "offsets/groups is NULL");
@@ -980,13 +989,16 @@ int rafthip_ingest_wire(rafthip_engine* e, const uint8_t* bytes, const uint64_t*
     uint8_t* d_status = nullptr;
     const bool msgs_host = out_msgs && !is_device_ptr(out_msgs);
     const bool status_host = out_status && !is_device_ptr(out_status);
-    if (out_msgs) {
-        if (msgs_host) {
-            if ((rc = wire_reserve(e, 3, (size_t)n * sizeof(Msg)))) return rc;
-            d_msgs = static_cast<Msg*>(e->wire_buf[3]);
-        } else {
-            d_msgs = reinterpret_cast<Msg*>(out_msgs);
-        }
+    if (out_msgs && !msgs_host) {
+        d_msgs = reinterpret_cast<Msg*>(out_msgs);
+    } else if (out_msgs || to_progress) {
+        if ((rc = wire_reserve(e, 3, (size_t)n * sizeof(Msg)))) return rc;
+        d_msgs = static_cast<Msg*>(e->wire_buf[3]);
+    }
+    u64* d_aux = nullptr;
+    if (to_progress) {
+        if ((rc = wire_reserve(e, 5, (size_t)n * sizeof(u64)))) return rc;
+        d_aux = static_cast<u64*>(e->wire_buf[5]);
     }
     if (out_status) {
         if (status_host) {
@@ -1004,8 +1016,18 @@ int rafthip_ingest_wire(rafthip_engine* e, const uint8_t* bytes, const uint64_t*
                            static_cast<const uint8_t*>(d_bytes), nbytes, static_cast<const u64*>(d_off) + off,
                            static_cast<const u32*>(d_groups) + off, m, e->G, e->S, static_cast<const u64*>(e->wire_hdr),
                            wire_hdr_words(e->S), e->match, e->stride, e->active, e->acks, e->mbytes,
-                           d_msgs ? d_msgs + off : nullptr, d_status ? d_status + off : nullptr, e->d_wire_counts);
+                           d_msgs ? d_msgs + off : nullptr, d_status ? d_status + off : nullptr, e->d_wire_counts,
+                           d_aux ? d_aux + off : nullptr);
         HIP_TRY(hipGetLastError());
+    }
+    const bool act_host = to_progress && (!actions || !is_device_ptr(actions));
+    uint8_t* d_act = actions;
+    if (to_progress) {
+        if (act_host) {
+            if ((rc = wire_reserve(e, 6, (size_t)n))) return rc;
+            d_act = static_cast<uint8_t*>(e->wire_buf[6]);
+        }
+        if ((rc = progress_passes(e, d_msgs, d_aux, n, d_act))) return rc;
     }
     bool wait = d_bytes != bytes || d_off != offsets || d_groups != groups;  // caller may reuse its host buffers
     if (msgs_host) {
@@ -1023,9 +1045,25 @@ int rafthip_ingest_wire(rafthip_engine* e, const uint8_t* bytes, const uint64_t*
                                hipMemcpyDeviceToHost, e->stream));
         wait = true;
     }
+    if (to_progress && actions && act_host) {
+        HIP_TRY(hipMemcpyAsync(actions, d_act, (size_t)n, hipMemcpyDeviceToHost, e->stream));
+        e->stats.bytes_downloaded += n;
+        wait = true;
+    }
     if (wait) HIP_TRY(hipStreamSynchronize(e->stream));
     e->stats.msgs_ingested += n;
     return RAFTHIP_OK;
+}
+
+int rafthip_ingest_wire(rafthip_engine* e, const uint8_t* bytes, const uint64_t* offsets, const uint32_t* groups,
+                        uint64_t n, rafthip_msg* out_msgs, uint8_t* out_status, uint64_t* status_counts) {
+    return wire_run(e, bytes, offsets, groups, n, out_msgs, out_status, status_counts, false, nullptr);
+}
+
+int rafthip_step_wire(rafthip_engine* e, const uint8_t* bytes, const uint64_t* offsets, const uint32_t* groups,
+                      uint64_t n, rafthip_msg* out_msgs, uint8_t* out_status, uint64_t* status_counts,
+                      uint8_t* actions) {
+    return wire_run(e, bytes, offsets, groups, n, out_msgs, out_status, status_counts, true, actions);
 }
 
 // ---- per-peer replication state (tracker.Progress, tracker.Inflights) --------
@@ -1037,7 +1075,7 @@ static_assert(kStepLimit == RAFTHIP_STEP_LIMIT && kActSendAppend == RAFTHIP_ACT_
                   kEvUnreachable == RAFTHIP_MSG_UNREACHABLE && kEvSnapStatus == RAFTHIP_MSG_SNAP_STATUS &&
                   kEvSentApp == RAFTHIP_MSG_SENT_APP && kEvSentSnap == RAFTHIP_MSG_SENT_SNAP &&
                   kStateProbe == RAFTHIP_STATE_PROBE && kStateReplicate == RAFTHIP_STATE_REPLICATE &&
-                  kStateSnapshot == RAFTHIP_STATE_SNAPSHOT,
+                  kStateSnapshot == RAFTHIP_STATE_SNAPSHOT && kEvNeedsHostRec == RAFTHIP_MSG_NEEDS_HOST,
               "progress constants");
 
 static int need_progress(const rafthip_engine* e) {
@@ -1205,6 +1243,26 @@ int rafthip_upload_first_index(rafthip_engine* e, uint64_t first, uint64_t count
     return RAFTHIP_OK;
 }
 
+// The link and apply passes over n device-resident records (d_act: device, n bytes).
+static int progress_passes(rafthip_engine* e, const Msg* d_msgs, const u64* d_aux, uint64_t n, uint8_t* d_act) {
+    int rc;
+    const size_t mb = (size_t)e->stride * e->mbytes;
+    if ((rc = ensure(e, e->active, mb))) return rc;
+    if ((rc = ensure(e, e->acks, mb))) return rc;
+    if ((rc = wire_reserve(e, 7, (size_t)n * sizeof(u32)))) return rc;
+    u32* prev = static_cast<u32*>(e->wire_buf[7]);
+    const u32 blocks = (u32)((n + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(k_progress_link, dim3(blocks), dim3(kBlock), 0, e->stream, d_msgs, (u32)n, e->G, e->S,
+                       e->stride, e->pp.rec, prev, e->term_last, d_act);
+    HIP_TRY(hipGetLastError());
+    e->pp.match = e->match;
+    hipLaunchKernelGGL(k_progress_apply, dim3(blocks), dim3(kBlock), 0, e->stream, d_msgs, d_aux, (u32)n, e->G, e->S,
+                       e->pp, static_cast<const u32*>(prev), e->active, e->acks, e->mbytes,
+                       static_cast<const u64*>(e->term_last), static_cast<const u64*>(e->first_index), d_act);
+    HIP_TRY(hipGetLastError());
+    return RAFTHIP_OK;
+}
+
 int rafthip_step_progress(rafthip_engine* e, const rafthip_msg* msgs, const uint64_t* aux, uint64_t n,
                           uint8_t* actions) {
     int rc = need_progress(e);
@@ -1227,18 +1285,7 @@ int rafthip_step_progress(rafthip_engine* e, const rafthip_msg* msgs, const uint
         if ((rc = wire_reserve(e, 6, (size_t)n))) return rc;
         d_act = static_cast<uint8_t*>(e->wire_buf[6]);
     }
-    if ((rc = wire_reserve(e, 7, (size_t)n * sizeof(u32)))) return rc;
-    u32* prev = static_cast<u32*>(e->wire_buf[7]);
-    const u32 blocks = (u32)((n + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(k_progress_link, dim3(blocks), dim3(kBlock), 0, e->stream, static_cast<const Msg*>(d_recs),
-                       (u32)n, e->G, e->S, e->stride, e->pp.rec, prev, e->term_last, d_act);
-    HIP_TRY(hipGetLastError());
-    e->pp.match = e->match;
-    hipLaunchKernelGGL(k_progress_apply, dim3(blocks), dim3(kBlock), 0, e->stream, static_cast<const Msg*>(d_recs),
-                       static_cast<const u64*>(d_aux), (u32)n, e->G, e->S, e->pp,
-                       static_cast<const u32*>(prev), e->active, e->acks, e->mbytes,
-                       static_cast<const u64*>(e->term_last), static_cast<const u64*>(e->first_index), d_act);
-    HIP_TRY(hipGetLastError());
+    if ((rc = progress_passes(e, static_cast<const Msg*>(d_recs), static_cast<const u64*>(d_aux), n, d_act))) return rc;
     bool wait = staged || (aux && d_aux != aux);
     if (actions && act_host) {
         HIP_TRY(hipMemcpyAsync(actions, d_act, (size_t)n, hipMemcpyDeviceToHost, e->stream));

@@ -27,14 +27,16 @@ enum : uint8_t {  // = RAFTHIP_WIRE_*
     kWireNested = 5,
     kWireMalformed = 6,
     kWireBadGroup = 7,
-    kWireStatuses = 8,
+    kWireNeedsLog = 8,  // rafthip_step_wire only
+    kWireStatuses = 9,
 };
+constexpr uint8_t kEvNeedsHost = 0xFE;  // record type of a kWireNeedsLog message (progress.h)
 constexpr uint8_t kMsgFlagHasCtx = 2;
 constexpr uint8_t kWireNoSlot = 0xFF;
 
 struct WireFields {
     u32 type;      // int32 MessageType: the low 32 bits of the varint
-    u64 from, term, index;
+    u64 from, term, index, log_term, reject_hint;
     bool reject;
     bool nested;   // a non-empty entries / snapshot / responses payload was seen
     u64 ctx;       // first min(ctx_len, 8) bytes of Context, little-endian
@@ -112,7 +114,7 @@ __device__ bool wire_skip(const R& rd, i64& pos, i64 end) {
 template <class R>
 __device__ bool wire_parse(const R& rd, i64 pos, i64 end, WireFields& f) {
     f.type = 0;
-    f.from = f.term = f.index = 0;
+    f.from = f.term = f.index = f.log_term = f.reject_hint = 0;
     f.reject = f.nested = false;
     f.ctx = f.ctx_len = 0;
     while (pos < end) {
@@ -131,8 +133,10 @@ __device__ bool wire_parse(const R& rd, i64 pos, i64 end, WireFields& f) {
                 if (field == 1) f.type = (u32)v;
                 else if (field == 3) f.from = v;
                 else if (field == 4) f.term = v;
+                else if (field == 5) f.log_term = v;
                 else if (field == 6) f.index = v;
                 else if (field == 10) f.reject = v != 0;
+                else if (field == 11) f.reject_hint = v;
                 break;
             }
             case 7: case 9: case 12: case 14: {
@@ -172,7 +176,8 @@ __global__ __launch_bounds__(kWireBlock) void k_ingest_wire(
     const u32* __restrict__ groups, u64 n, u64 G, u32 S, const u64* __restrict__ hdr /* [G][H] */, u32 H,
     u64* __restrict__ match, u64 stride,
     void* __restrict__ active, void* __restrict__ acks, int mbytes, Msg* __restrict__ out_msgs,
-    uint8_t* __restrict__ out_status, u64* __restrict__ counters /* [kWireStatuses] */) {
+    uint8_t* __restrict__ out_status, u64* __restrict__ counters /* [kWireStatuses] */,
+    u64* __restrict__ out_aux /* non-NULL: decode only, the records go on to the Progress stepper */) {
     __shared__ __align__(16) uint8_t sm[kWireLdsBytes + 32];
     __shared__ u32 hist[kWireStatuses];
     const u64 i0 = (u64)blockIdx.x * kWireBlock;
@@ -222,7 +227,11 @@ __global__ __launch_bounds__(kWireBlock) void k_ingest_wire(
         }
         u32 slot = kWireNoSlot;
         uint8_t flags = 0;
+        u32 rec_type = 0xFFu;
+        u64 aux = 0;
+        const bool apply = out_aux == nullptr;
         if (decoded) {
+            rec_type = f.type <= 0xFFu ? f.type : 0xFFu;
             if (f.ctx_len > 0) flags |= kMsgFlagHasCtx;
             const bool app = f.type == kMsgAppResp, hb = f.type == kMsgHeartbeatResp;
             if (!app && !hb) {
@@ -248,14 +257,26 @@ __global__ __launch_bounds__(kWireBlock) void k_ingest_wire(
                     if (slot == kWireNoSlot) {
                         status = kWireNoProgress;
                     } else {
-                        or_slot_bit(active, mbytes, group, slot);  // raft.go:1337,1528
+                        if (apply) or_slot_bit(active, mbytes, group, slot);  // raft.go:1337,1528
                         if (app) {
-                            if (!f.reject) atomicMax(match + (u64)slot * stride + group, f.index);  // :1477
+                            if (!apply) {
+                                // nextProbeIdx is RejectHint unless LogTerm > 0 asks for
+                                // findConflictByTerm on the leader's log (raft.go:1362-1459): the host's
+                                if (f.reject) {
+                                    aux = f.reject_hint;
+                                    if (f.log_term > 0) {
+                                        status = kWireNeedsLog;
+                                        rec_type = kEvNeedsHost;
+                                    }
+                                }
+                            } else if (!f.reject) {
+                                atomicMax(match + (u64)slot * stride + group, f.index);  // :1477
+                            }
                         } else {
                             const u64 want = row[kHdrCtxLen];
                             if (want != 0 && f.ctx_len == want && f.ctx == row[kHdrCtx]) {
                                 flags |= kMsgFlagCtx;
-                                or_slot_bit(acks, mbytes, group, slot);  // read_only.go:68-76
+                                if (apply) or_slot_bit(acks, mbytes, group, slot);  // read_only.go:68-76
                             }
                         }
                     }
@@ -264,13 +285,13 @@ __global__ __launch_bounds__(kWireBlock) void k_ingest_wire(
         }
         if (out_msgs) {
             Vec<u64, 2> o;
-            const u32 type8 = decoded ? (f.type <= 0xFFu ? f.type : 0xFFu) : 0xFFu;
-            o.v[0] = (u64)group | ((u64)(slot & 0xFFu) << 32) | ((u64)type8 << 40) |
+            o.v[0] = (u64)group | ((u64)(slot & 0xFFu) << 32) | ((u64)rec_type << 40) |
                      ((u64)(decoded && f.reject ? 1 : 0) << 48) | ((u64)flags << 56);
             o.v[1] = decoded ? f.index : 0;
             store_vec<u64, 2>(reinterpret_cast<u64*>(out_msgs + i), o);
         }
         if (out_status) out_status[i] = status;
+        if (out_aux) out_aux[i] = aux;
         atomicAdd(&hist[status], 1u);
     }
     __syncthreads();

@@ -36,7 +36,7 @@ def run_both(oracle, e, state, data, offsets, groups, device_inputs=False):
     else:
         msgs, status, counts = e.ingest_wire(data, offsets, groups)
     assert np.array_equal(status, want_status)
-    assert np.array_equal(counts, want_counts)
+    assert np.array_equal(counts[:8], want_counts) and counts[8] == 0
     assert np.array_equal(msgs, want_msgs)
     assert np.array_equal(e.read_match(), wm)
     assert np.array_equal(e.read_active(), wa)
@@ -160,7 +160,7 @@ def test_ingest_wire_then_commit_full_size(oracle):
         e.upload_term(term)
         e.upload_read_ctx(cw, cl)
         _, status, counts = e.ingest_wire(data, offsets, groups, want_msgs=False)
-        assert np.array_equal(counts, want_counts) and np.array_equal(status, want_status)
+        assert np.array_equal(counts[:8], want_counts) and np.array_equal(status, want_status)
         assert counts[capi.WIRE_APPLIED] > 0.8 * n
         e.commit()
         assert np.array_equal(e.read_match(), wm)
@@ -168,3 +168,70 @@ def test_ingest_wire_then_commit_full_size(oracle):
         assert np.array_equal(e.read_acks(), wk)
         assert np.array_equal(e.read_commit(), oracle.batch_committed(wm, uniform_voters=V, threads=0))
         assert (wm != match).any() and wk.any()
+
+
+@pytest.mark.parametrize("S,cap", [(3, 4), (9, 2), (16, 8), (40, 3)])
+def test_step_wire_feeds_the_progress_stepper(oracle, S, cap):
+    """rafthip_step_wire = the wire decode of rafthip_ingest_wire + rafthip_step_progress on the decoded
+    records: rejections probe at RejectHint when LogTerm is 0 and go to the host (status 8, later events
+    of that Progress deferred) when it is not."""
+    import progress_util as pu
+    from oracle import pyoracle as po
+    rng = np.random.default_rng(1700 + S)
+    G, n = 499, 20000
+    ids, term, ctxs, _, _, _ = make_state(rng, S, G)
+    pl = pu.random_planes(rng, S, G, cap, 0)
+    blobs, groups = wu.random_batch(rng, n, G, ids, term, ctxs)
+    # rejections: some with LogTerm 0 (an old follower, raft.go:1343-1345), aimed at Next-1 so that they bite
+    for i in range(0, n, 9):
+        g = int(groups[i]) % G
+        s = int(rng.integers(0, S))
+        if ids[s, g] == 0:
+            continue
+        groups[i] = g
+        blobs[i] = wu.encode_message(type=wu.MSG_APP_RESP, frm=int(ids[s, g]), term=int(term[g]),
+                                     index=int(pl["next"][s, g]) - 1, reject=True,
+                                     rejectHint=int(pl["match"][s, g]) + int(rng.integers(0, 3)),
+                                     logTerm=0 if rng.random() < 0.6 else 3)
+    data, offsets = wu.pack(blobs)
+    cw, cl = wu.ctx_words(ctxs)
+    last = pl["match"].max(axis=0) + np.uint64(5)
+    first = np.zeros(G, dtype=np.uint64)
+    active, acks = pu.mask_planes(S, G)
+    want_msgs, want_aux, want_status, want_counts = oracle.decode_wire_msgs(ids, term, cw, cl, data, offsets, groups)
+    assert want_counts[capi.WIRE_NEEDS_LOG] > 50 and (want_msgs["type"][want_status == 8] == capi.MSG_NEEDS_HOST).all()
+    with raft_amd.Engine(G, S) as e:
+        e.progress_config(cap, 0)
+        e.upload_match(pl["match"])
+        e.upload_progress(pl["pstate"], pl["next"], pl["pending"])
+        e.upload_inflights(pl["infl_meta"], pl["infl_bytes"], pl["ring_index"], pl["ring_bytes"])
+        e.upload_active(active)
+        e.upload_acks(acks)
+        e.upload_term_range(np.zeros(G, dtype=np.uint64), last)
+        e.upload_first_index(first)
+        e.upload_ids(ids)
+        e.upload_term(term)
+        e.upload_read_ctx(cw, cl)
+        msgs, status, counts, act = e.step_wire(data, offsets, groups)
+        assert np.array_equal(status, want_status) and np.array_equal(counts, want_counts)
+        assert np.array_equal(msgs, want_msgs)
+        want_act = po.step_progress(pl, cap, 0, active, acks, last, first, want_msgs, want_aux)
+        assert np.array_equal(act, want_act)
+        got = e.read_progress()
+        for k in ("pstate", "next", "pending", "infl_meta", "infl_bytes", "ring_index", "ring_bytes"):
+            assert np.array_equal(got[k], pl[k]), k
+        assert np.array_equal(e.read_match(), pl["match"])
+        assert np.array_equal(e.read_active(), active) and np.array_equal(e.read_acks(), acks)
+        # every needs-log message is deferred, and so is everything after it on its Progress
+        nl = np.flatnonzero(want_status == 8)
+        assert (want_act[nl] == capi.ACT_DEFERRED).all()
+        applied_rejects = (want_status == 0) & (want_msgs["reject"] != 0) & (want_msgs["type"] == 4)
+        assert (want_act[applied_rejects] & capi.ACT_SEND_APPEND).any()
+        # the host steps what came back: hint from its log (here: RejectHint itself), then the deferred rest
+        idx = np.flatnonzero(want_act == capi.ACT_DEFERRED)
+        redo = want_msgs[idx].copy()
+        redo["type"][redo["type"] == capi.MSG_NEEDS_HOST] = capi.MSG_APP_RESP
+        a2 = e.step_progress(redo, np.ascontiguousarray(want_aux[idx]))
+        w2 = po.step_progress(pl, cap, 0, active, acks, last, first, redo, np.ascontiguousarray(want_aux[idx]))
+        assert np.array_equal(a2, w2) and (w2 & capi.ACT_DEFERRED == 0).all()
+        assert np.array_equal(e.read_progress()["next"], pl["next"])

@@ -180,3 +180,21 @@ def test_deferral_is_all_or_nothing_per_progress():
     act = po.step_progress(pl, cap, 0, a, k, np.zeros(G, dtype=np.uint64), np.zeros(G, dtype=np.uint64), msgs)
     assert (act[:66] == po.ACT_DEFERRED).all() and (act[66:] & po.ACT_DEFERRED == 0).all()
     assert pl["pstate"][0, 1] == before["pstate"][0, 1] and int(a[1]) == 0 and int(a[2]) == 1
+
+
+def test_a_host_only_event_blocks_the_rest_of_its_progress():
+    rng = np.random.default_rng(13)
+    S, G, cap = 2, 4, 4
+    pl = pu.random_planes(rng, S, G, cap, 0)
+    before = {k: v.copy() for k, v in pl.items()}
+    msgs = np.zeros(6, dtype=pu.MSG_DTYPE)
+    msgs["type"] = [po.EV_HEARTBEAT_RESP, po.EV_NEEDS_HOST, po.EV_HEARTBEAT_RESP, po.EV_HEARTBEAT_RESP, po.EV_UNREACHABLE,
+                    po.EV_HEARTBEAT_RESP]
+    msgs["group"] = [1, 1, 1, 2, 1, 1]
+    msgs["slot"] = [0, 0, 0, 0, 1, 0]
+    a, k = pu.mask_planes(S, G)
+    act = po.step_progress(pl, cap, 0, a, k, np.zeros(G, dtype=np.uint64), np.zeros(G, dtype=np.uint64), msgs)
+    D = po.ACT_DEFERRED
+    assert [bool(x & D) for x in act] == [False, True, True, False, False, True]
+    assert (pl["pstate"][0, 1] & 4) == 0  # the first heartbeat response was stepped
+    assert pl["next"][0, 1] == before["next"][0, 1]
