@@ -8,10 +8,28 @@ import os
 import numpy as np
 
 import golden_util as gu
-from oracle import pyoracle as po
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-MSG_DTYPE = po.MSG_DTYPE
+MSG_DTYPE = np.dtype([("group", "<u4"), ("slot", "u1"), ("type", "u1"), ("reject", "u1"), ("flags", "u1"),
+                      ("index", "<u8")])
+
+
+class po:  # the event / action / state numbers (= oracle.pyoracle's and raft_amd.capi's; tests/test_progress_cpu.py
+    # checks both) — kept here so that the generators below load neither the oracle nor the engine
+    STATE_PROBE, STATE_REPLICATE, STATE_SNAPSHOT = 0, 1, 2
+    STATE_NAMES = {"StateProbe": 0, "StateReplicate": 1, "StateSnapshot": 2}
+    EV_APP_RESP, EV_HEARTBEAT_RESP, EV_UNREACHABLE, EV_SNAP_STATUS = 4, 9, 10, 11
+    EV_APPENDED, EV_SENT_APP, EV_SENT_SNAP, EV_NEEDS_HOST = 0xF0, 0xF1, 0xF2, 0xFE
+    ACT_SEND_APPEND, ACT_UPDATED, ACT_WAS_PAUSED, ACT_CAUGHT_UP, ACT_ERROR, ACT_DEFERRED, ACT_DROPPED = 1, 2, 4, 8, 32, 64, 128
+    STEP_LIMIT = 64
+
+    @staticmethod
+    def progress_planes(S, G, cap):
+        return {"match": np.zeros((S, G), dtype=np.uint64), "next": np.zeros((S, G), dtype=np.uint64),
+                "pstate": np.zeros((S, G), dtype=np.uint8), "pending": np.zeros((S, G), dtype=np.uint64),
+                "infl_meta": np.zeros((S, G), dtype=np.uint32), "infl_bytes": np.zeros((S, G), dtype=np.uint64),
+                "ring_index": np.zeros((max(cap, 1), S, G), dtype=np.uint64),
+                "ring_bytes": np.zeros((max(cap, 1), S, G), dtype=np.uint64)}
 
 EV = {"app_resp": po.EV_APP_RESP, "heartbeat_resp": po.EV_HEARTBEAT_RESP, "unreachable": po.EV_UNREACHABLE,
       "snap_status": po.EV_SNAP_STATUS, "appended": po.EV_APPENDED, "sent_app": po.EV_SENT_APP,

@@ -198,3 +198,16 @@ def test_a_host_only_event_blocks_the_rest_of_its_progress():
     assert [bool(x & D) for x in act] == [False, True, True, False, False, True]
     assert (pl["pstate"][0, 1] & 4) == 0  # the first heartbeat response was stepped
     assert pl["next"][0, 1] == before["next"][0, 1]
+
+
+def test_shared_numbers_agree():
+    from raft_amd import capi
+    for name in ("STATE_PROBE", "STATE_REPLICATE", "STATE_SNAPSHOT", "ACT_SEND_APPEND", "ACT_UPDATED", "ACT_WAS_PAUSED",
+                 "ACT_CAUGHT_UP", "ACT_ERROR", "ACT_DEFERRED", "ACT_DROPPED", "STEP_LIMIT"):
+        assert getattr(pu.po, name) == getattr(po, name) == getattr(capi, name), name
+    for name in ("EV_APP_RESP", "EV_HEARTBEAT_RESP", "EV_UNREACHABLE", "EV_SNAP_STATUS", "EV_APPENDED", "EV_SENT_APP",
+                 "EV_SENT_SNAP", "EV_NEEDS_HOST", "STATE_NAMES"):
+        assert getattr(pu.po, name) == getattr(po, name), name
+    assert pu.MSG_DTYPE == po.MSG_DTYPE == capi.MSG_DTYPE
+    assert (capi.MSG_UNREACHABLE, capi.MSG_SNAP_STATUS, capi.MSG_SENT_APP, capi.MSG_SENT_SNAP, capi.MSG_NEEDS_HOST) == (
+        po.EV_UNREACHABLE, po.EV_SNAP_STATUS, po.EV_SENT_APP, po.EV_SENT_SNAP, po.EV_NEEDS_HOST)
