@@ -115,7 +115,7 @@ def main():
 
     stream = torch.cuda.Stream(device=dev)
     engines = []
-    first_match = None
+    mats = []
     for b in range(args.batches):
         # group-id range of this rank's shard of batch b: seeds differ per (rank, batch)
         m = splitmix_batch(0x5EED0000 + 1000 * rank + b, VOTERS, G_BATCH)
@@ -123,8 +123,8 @@ def main():
         e.set_uniform_config(VOTERS)
         e.upload_match(m)
         engines.append(e)
-        if b == 0:
-            first_match = m
+        mats.append(m)
+    first_match = mats[0]
 
     def barrier():
         if world > 1:
@@ -210,6 +210,33 @@ def main():
     except Exception as ex:  # capture is a measurement extra, never the headline
         extra["hip_graph_avg_launch_us"] = None
         extra["hip_graph_error"] = str(ex)[:200]
+
+    # the same rotation with every engine on its OWN stream (what rafthip_create gives an engine by
+    # default): passes over different engines are independent, so one pass's drain overlaps the
+    # next one's ramp-up.  Aggregate throughput of a host with several shards per GPU; not `value`
+    # (the headline keeps one stream so that its per-launch duration is the kernel's own).
+    if rank == 0 and world == 1:
+        own = []
+        for m in mats:
+            e = raft_amd.Engine(G_BATCH, VOTERS, device=local_rank)
+            e.set_uniform_config(VOTERS)
+            e.upload_match(m)
+            own.append(e)
+        for i in range(200):
+            own[i % len(own)].commit()
+        torch.cuda.synchronize()
+        a = time.perf_counter()
+        for i in range(args.steps):
+            own[i % len(own)].commit()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - a
+        extra["own_stream_engines_groups_per_s"] = args.steps * G_BATCH / dt
+        extra["own_stream_engines_GBs"] = round(args.steps * G_BATCH * BYTES_PER_GROUP / dt / 1e9, 1)
+        if not np.array_equal(own[0].read_commit()[idx], want):
+            raise SystemExit("bench: own-stream result differs from the oracle")
+        for e in own:
+            e.close()
+    del mats
 
     # on-box streaming ceiling: a device-to-device copy of 1 GiB, read + write bytes
     if rank == 0:
