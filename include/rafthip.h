@@ -214,6 +214,15 @@ int rafthip_upload_commit(rafthip_engine *e, uint64_t first, uint64_t count, con
  * raft.go:1327-1331). */
 int rafthip_scatter_acks(rafthip_engine *e, const rafthip_ack *recs, uint64_t n);
 
+/* The same MaybeUpdate when the tick's acks are a dense plane rather than a
+ * record stream: acks[s*src_stride + g] = the index slot s of group first+g
+ * acknowledged, 0 = nothing; Match = max(Match, ack) cell by cell
+ * (tracker/progress.go:168-177).  Streams at HBM rate (24 B per cell) instead
+ * of one scattered atomic per ack: the better form once more than about one
+ * cell in ten carries an ack.  acks may be host or device memory. */
+int rafthip_merge_acks(rafthip_engine *e, uint64_t first, uint64_t count, const uint64_t *acks,
+                       uint64_t src_stride);
+
 /* stepLeader's bookkeeping for a batch of responses — raft.go:1327-1561:
  *   MsgAppResp:       pr.RecentActive = true (raft.go:1337); unless Reject,
  *                     pr.MaybeUpdate(m.Index) (raft.go:1477 -> tracker/progress.go:168-177)

@@ -42,6 +42,7 @@ SYMBOLS = [
     "rafthip_upload_ids", "rafthip_upload_term", "rafthip_upload_read_ctx", "rafthip_ingest_wire",
     "rafthip_progress_config", "rafthip_upload_progress", "rafthip_read_progress", "rafthip_upload_inflights",
     "rafthip_read_inflights", "rafthip_upload_first_index", "rafthip_step_progress", "rafthip_step_wire",
+    "rafthip_merge_acks",
 ]
 
 STATE_PROBE, STATE_REPLICATE, STATE_SNAPSHOT, PROGRESS_PAUSED = 0, 1, 2, 4
@@ -165,6 +166,7 @@ def load_library():
         "rafthip_upload_first_index": (i32, [vp, u64, u64, vp]),
         "rafthip_step_progress": (i32, [vp, vp, vp, u64, vp]),
         "rafthip_step_wire": (i32, [vp, vp, vp, vp, u64, vp, vp, vp, vp]),
+        "rafthip_merge_acks": (i32, [vp, u64, u64, vp, u64]),
     }
     assert sorted(sig) == sorted(SYMBOLS)
     for name, (res, args) in sig.items():
@@ -284,6 +286,11 @@ class Engine:
         if n is None:
             n = len(recs)
         _check(self._L.rafthip_scatter_acks(self._h, _ptr(recs), n))
+
+    def merge_acks(self, acks, first=0, count=None, stride=None):
+        """acks: u64 [S][count] plane (numpy, torch or raw device pointer with stride), 0 = no ack."""
+        first, count = self._range(first, count)
+        _check(self._L.rafthip_merge_acks(self._h, first, count, _ptr(acks), count if stride is None else stride))
 
     def commit(self):
         _check(self._L.rafthip_commit(self._h))

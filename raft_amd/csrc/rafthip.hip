@@ -812,6 +812,34 @@ int rafthip_scatter_acks(rafthip_engine* e, const rafthip_ack* recs, uint64_t n)
     return RAFTHIP_OK;
 }
 
+int rafthip_merge_acks(rafthip_engine* e, uint64_t first, uint64_t count, const uint64_t* acks,
+                       uint64_t src_stride) {
+    int rc = check_range(e, first, count);
+    if (rc) return rc;
+    if (!acks) return fail(RAFTHIP_EINVAL, "acks is NULL");
+    if (src_stride < count) return fail(RAFTHIP_EINVAL, "src_stride %llu < count %llu", (u64)src_stride, (u64)count);
+    if (count == 0) return RAFTHIP_OK;
+    DeviceGuard guard(e->device);
+    const u64* d_acks = reinterpret_cast<const u64*>(acks);
+    u64 d_stride = src_stride;
+    bool staged = false;
+    if (!is_device_ptr(acks)) {  // host plane: staged through the engine's growable buffer, packed to pitch = count
+        d_stride = (count + 1) & ~1ull;
+        if ((rc = wire_reserve(e, 5, (size_t)d_stride * e->S * sizeof(u64)))) return rc;
+        if ((rc = copy_rows(e, e->wire_buf[5], d_stride * 8, acks, src_stride * 8, count * 8, e->S))) return rc;
+        d_acks = static_cast<const u64*>(e->wire_buf[5]);
+        e->stats.bytes_uploaded += count * 8 * e->S;
+        staged = true;
+    }
+    const u32 blocks = (u32)(((count + 1) / 2 + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(k_merge_acks, dim3(blocks), dim3(kBlock), 0, e->stream, e->match, e->stride, d_acks, d_stride,
+                       (u64)first, (u64)count, e->S);
+    HIP_TRY(hipGetLastError());
+    if (staged) HIP_TRY(hipStreamSynchronize(e->stream));
+    e->stats.acks_applied += count * e->S;
+    return RAFTHIP_OK;
+}
+
 int rafthip_ingest_msgs(rafthip_engine* e, const rafthip_msg* msgs, uint64_t n) {
     if (!e) return fail(RAFTHIP_EINVAL, "engine is NULL");
     if (n == 0) return RAFTHIP_OK;

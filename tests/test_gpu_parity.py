@@ -272,6 +272,50 @@ def test_scatter_then_commit(oracle, S, G):
         assert st["acks_applied"] == N
 
 
+@pytest.mark.parametrize("S,G", [(9, 4001), (3, 70002), (20, 999), (1, 1), (64, 130)])
+def test_merge_acks_equals_the_ack_stream(oracle, S, G):
+    """The tick's acks as a dense [slot][group] plane (0 = none): the same Match as stepping the
+    equivalent ack records one by one (Progress.MaybeUpdate, tracker/progress.go:168-177); host and
+    device planes, sub-ranges at odd offsets, values >= 2^63."""
+    import torch
+    rng = np.random.default_rng(550 + S)
+    match = rng.integers(0, 1 << 40, size=(S, G), dtype=np.uint64)
+    match[rng.random((S, G)) < 0.02] |= np.uint64(1) << np.uint64(63)
+    plane = np.where(rng.random((S, G)) < 0.45, match + rng.integers(0, 64, size=(S, G)).astype(np.uint64)
+                     - np.minimum(match, 16), 0).astype(np.uint64)
+    plane[rng.random((S, G)) < 0.01] = np.uint64((1 << 64) - 1)
+    plane = np.ascontiguousarray(plane)
+    ss, gg = np.nonzero(plane)
+    recs = np.zeros(len(ss), dtype=raft_amd.ACK_DTYPE)
+    recs["slot"], recs["group"], recs["index"] = ss, gg, plane[ss, gg]
+    want = match.copy()
+    assert oracle.scatter_acks(want, recs) == 0
+    assert np.array_equal(want, np.maximum(match, plane))
+    with raft_amd.Engine(G, S) as e:
+        e.upload_match(match)
+        e.merge_acks(plane)
+        assert np.array_equal(e.read_match(), want)
+        e.merge_acks(plane)  # idempotent
+        assert np.array_equal(e.read_match(), want)
+        # device plane with a pitch, and an odd sub-range from the host
+        e.upload_match(match)
+        pitch = G + 6
+        d = torch.zeros((S, pitch), dtype=torch.int64, device="cuda")
+        d[:, :G] = torch.from_numpy(plane.view(np.int64)).cuda()
+        e.merge_acks(d, stride=pitch)
+        e.synchronize()
+        assert np.array_equal(e.read_match(), want)
+        if G > 8:
+            e.upload_match(match)
+            lo, cnt = 3, G - 7
+            e.merge_acks(np.ascontiguousarray(plane[:, lo:lo + cnt]), first=lo, count=cnt)
+            w2 = match.copy()
+            w2[:, lo:lo + cnt] = want[:, lo:lo + cnt]
+            assert np.array_equal(e.read_match(), w2)
+        with pytest.raises(raft_amd.RafthipError):
+            e.merge_acks(plane, first=1, count=G)
+
+
 @pytest.mark.parametrize("S,uniform,flags", [(5, True, 0), (6, False, 0), (12, False, 0), (12, False, 1), (40, False, 0),
                                               (12, True, 0)])
 def test_commit_changed_pairs(oracle, S, uniform, flags):

@@ -245,6 +245,18 @@ def main():
             timed("k_progress_link + k_progress_apply, random cells (K9)", "event", N, 106,
                   lambda: L.rafthip_step_progress(e._h, d_ev.data_ptr(), d_aux.data_ptr(), N, d_act.data_ptr()))
         del pl, ev, aux, d_ev, d_aux, d_act
+    # the same 4*G acks as a dense [slot][group] plane (K5d)
+    if not args.only or args.only in "k_merge_acks, dense plane (K5d)":
+        plane = np.zeros((Sv, G), dtype=np.uint64)
+        np.maximum.at(plane, (recs["slot"], recs["group"]), recs["index"])
+        d_plane = torch.from_numpy(plane.view(np.int64)).to(dev)
+        with raft_amd.Engine(G, Sv, stream=stream.cuda_stream) as e:
+            e.set_uniform_config(7)
+            # every launch must really move its cells: Match is re-seeded below the plane each time
+            low = m & np.uint64((1 << 40) - 1)
+            timed("k_merge_acks, dense plane, %.0f %% of cells acked (K5d)" % (100.0 * np.count_nonzero(plane) / plane.size),
+                  "cell", Sv * G, 24, lambda: e.merge_acks(d_plane), setup=lambda: e.upload_match(low), iters=5)
+        del plane, d_plane
     # sorted-by-group stream (a host that buckets acks by range)
     order = np.argsort(recs["group"], kind="stable")
     d_recs = torch.from_numpy(np.ascontiguousarray(recs[order]).view(np.uint8)).to(dev)
