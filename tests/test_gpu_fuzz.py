@@ -6,7 +6,9 @@ import numpy as np
 import pytest
 
 import golden_util as gu
+import progress_util as pu
 import raft_amd
+from oracle import pyoracle as po
 from test_gpu_parity import rand_masks, rand_match
 
 pytestmark = pytest.mark.gpu
@@ -45,15 +47,22 @@ def test_random_call_sequences(oracle, S, G, seed):
             kw["learner_mask"] = np.zeros(G, mdt)
         return kw
 
+    cap, max_bytes = 3, 100
+    pl = po.progress_planes(S, G, cap)  # the per-peer replication state; its Match plane IS sh["match"]
+    pl["match"] = sh["match"]
+    first_index = np.zeros(G, np.uint64)
+    PKEYS = ("pstate", "next", "pending", "infl_meta", "infl_bytes", "ring_index", "ring_bytes")
+
     with raft_amd.Engine(G, S) as e:
         e.upload_active(sh["active"])
         e.upload_acks(sh["acks"])
         e.upload_self(sh["self"])
         e.upload_term_range(sh["tf"], sh["tl"])
         e.reset_votes()
-        for step in range(120):
-            op = int(rng.integers(0, 16))
-            checked[0] += op >= 10
+        e.progress_config(cap, max_bytes)
+        for step in range(150):
+            op = int(rng.integers(0, 20))
+            checked[0] += 10 <= op < 16
             a, n = rng_range()
             if op == 0:
                 part = rand_match(rng, S, max(n, 1))[:, :n]
@@ -107,6 +116,34 @@ def test_random_call_sequences(oracle, S, G, seed):
                 msgs["index"] = rng.integers(0, 50, size=k)
                 e.ingest_msgs(msgs)
                 oracle.step_leader_msgs(sh["match"], sh["active"], sh["acks"], sh["tl"], msgs)
+            elif op == 16:
+                plane = np.where(rng.random((S, n)) < 0.4, rng.integers(0, 60, size=(S, n)), 0).astype(np.uint64)
+                pad = np.zeros((S, n + 2), np.uint64)
+                pad[:, :n] = plane
+                e.merge_acks(pad, first=a, count=n, stride=n + 2)
+                sh["match"][:, a:a + n] = np.maximum(sh["match"][:, a:a + n], plane)
+            elif op == 17:
+                st = rng.integers(0, 3, size=(S, n)).astype(np.uint8) | (rng.integers(0, 2, size=(S, n)).astype(np.uint8) << 2)
+                nx = sh["match"][:, a:a + n] + rng.integers(1, 5, size=(S, n)).astype(np.uint64)
+                pn = np.where((st & 3) == 2, rng.integers(0, 60, size=(S, n)), 0).astype(np.uint64)
+                e.upload_progress(np.ascontiguousarray(st), np.ascontiguousarray(nx), np.ascontiguousarray(pn), first=a,
+                                  count=n)
+                pl["pstate"][:, a:a + n], pl["next"][:, a:a + n], pl["pending"][:, a:a + n] = st, nx, pn
+                pl["infl_meta"][:, a:a + n] = 0
+                pl["infl_bytes"][:, a:a + n] = 0
+                fi = rng.integers(0, 30, size=n).astype(np.uint64)
+                e.upload_first_index(fi, first=a, count=n)
+                first_index[a:a + n] = fi
+            elif op in (18, 19):
+                k = int(rng.integers(0, 600))
+                msgs, aux = pu.random_events(rng, k, S, G, pl, hot_cells=int(rng.integers(0, 4)))
+                act = e.step_progress(msgs, aux)
+                want = po.step_progress(pl, cap, max_bytes, sh["active"], sh["acks"], sh["tl"], first_index, msgs, aux)
+                assert np.array_equal(act, want), step
+                got = e.read_progress()
+                for key in PKEYS:
+                    assert np.array_equal(got[key], pl[key]), (step, key)
+                assert np.array_equal(e.read_match(), sh["match"]), step
             elif op == 10:
                 e.commit()
                 sh["commit"] = oracle.batch_committed(sh["match"], **cfg_kw())
@@ -158,3 +195,6 @@ def test_random_call_sequences(oracle, S, G, seed):
         assert np.array_equal(e.read_match(), sh["match"])
         assert np.array_equal(e.read_acks(), sh["acks"])
         assert np.array_equal(e.read_term_range()[1], sh["tl"])
+        got = e.read_progress()
+        for key in PKEYS:
+            assert np.array_equal(got[key], pl[key]), key
