@@ -137,6 +137,14 @@ uint32_t rafthip_abi_version(void);
 const char *rafthip_last_error(void);
 int rafthip_device_count(int *count);
 
+/* Page-locked host memory for the buffers a host fills every tick (ack / message
+ * records, serialized bytes, pair landing buffers): uploads from it run at the
+ * link rate instead of through the runtime's pageable staging copies.  No
+ * counterpart in the reference; any host pointer is accepted everywhere, this
+ * is the fast kind.  Free with rafthip_host_free. */
+int rafthip_host_alloc(void **ptr, uint64_t bytes);
+int rafthip_host_free(void *ptr);
+
 /* Stands where tracker.MakeProgressTracker (tracker/tracker.go:129-145) stands
  * per group: allocates zeroed planes; config is "empty" (both halves empty,
  * which commits MaxUint64 / wins votes, majority.go:128-132,179-184). */

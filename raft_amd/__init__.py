@@ -9,6 +9,6 @@ ABI in include/rafthip.h).  This package is host-side plumbing over that ABI:
 There is no CPU compute path here: without the built library and a gfx950 GPU
 every call fails loudly.
 """
-from .capi import (Engine, RafthipError, batch_committed_index, batch_vote_result,  # noqa: F401
+from .capi import (Engine, PinnedArray, RafthipError, batch_committed_index, batch_vote_result,  # noqa: F401
                    library_path, load_library, ACK_DTYPE, PAIR_DTYPE, MSG_DTYPE, mask_dtype,
                    MSG_APP_RESP, MSG_HEARTBEAT_RESP, MSG_APPENDED, MSGF_READ_CTX)

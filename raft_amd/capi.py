@@ -42,7 +42,7 @@ SYMBOLS = [
     "rafthip_upload_ids", "rafthip_upload_term", "rafthip_upload_read_ctx", "rafthip_ingest_wire",
     "rafthip_progress_config", "rafthip_upload_progress", "rafthip_read_progress", "rafthip_upload_inflights",
     "rafthip_read_inflights", "rafthip_upload_first_index", "rafthip_step_progress", "rafthip_step_wire",
-    "rafthip_merge_acks",
+    "rafthip_merge_acks", "rafthip_host_alloc", "rafthip_host_free",
 ]
 
 STATE_PROBE, STATE_REPLICATE, STATE_SNAPSHOT, PROGRESS_PAUSED = 0, 1, 2, 4
@@ -167,6 +167,8 @@ def load_library():
         "rafthip_step_progress": (i32, [vp, vp, vp, u64, vp]),
         "rafthip_step_wire": (i32, [vp, vp, vp, vp, u64, vp, vp, vp, vp]),
         "rafthip_merge_acks": (i32, [vp, u64, u64, vp, u64]),
+        "rafthip_host_alloc": (i32, [C.POINTER(vp), u64]),
+        "rafthip_host_free": (i32, [vp]),
     }
     assert sorted(sig) == sorted(SYMBOLS)
     for name, (res, args) in sig.items():
@@ -201,6 +203,31 @@ def _ptr(a):
             raise ValueError("tensor must be contiguous")
         return C.c_void_p(a.data_ptr())
     raise TypeError("unsupported buffer type %r" % type(a))
+
+
+class PinnedArray:
+    """A numpy array over page-locked host memory (rafthip_host_alloc); free() or use as a context manager."""
+
+    def __init__(self, shape, dtype):
+        self._L = load_library()
+        dtype = np.dtype(dtype)
+        n = int(np.prod(shape)) * dtype.itemsize
+        p = C.c_void_p()
+        _check(self._L.rafthip_host_alloc(C.byref(p), max(n, 1)))
+        self._p = p
+        self.array = np.frombuffer((C.c_char * max(n, 1)).from_address(p.value), dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def free(self):
+        if self._p is not None:
+            self.array = None
+            _check(self._L.rafthip_host_free(self._p))
+            self._p = None
+
+    def __enter__(self):
+        return self.array
+
+    def __exit__(self, *exc):
+        self.free()
 
 
 class Engine:

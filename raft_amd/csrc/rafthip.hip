@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <new>
 
 #include "kernels.h"
@@ -407,9 +408,20 @@ static int oneshot_engine(int device, uint64_t G, uint32_t S, const void* in_mas
 static int stage_records(rafthip_engine* e, const void* recs, uint64_t n, const void** d_recs, bool* staged) {
     hipPointerAttribute_t attr;
     *staged = false;
-    if (hipPointerGetAttributes(&attr, recs) == hipSuccess && attr.type == hipMemoryTypeDevice) {
-        *d_recs = recs;
-        return RAFTHIP_OK;
+    if (hipPointerGetAttributes(&attr, recs) == hipSuccess) {
+        if (attr.type == hipMemoryTypeDevice) {
+            *d_recs = recs;
+            return RAFTHIP_OK;
+        }
+        if (attr.type == hipMemoryTypeHost && attr.devicePointer && !getenv("RAFTHIP_NO_ZERO_COPY")) {
+            // page-locked host memory (rafthip_host_alloc): the kernel streams the records over the
+            // link itself — copy and compute in one pass, no staging buffer.  The caller's buffer is
+            // in use until the kernel is done: report it as staged so that the call waits.
+            *d_recs = attr.devicePointer;
+            *staged = true;
+            e->stats.bytes_uploaded += n * sizeof(Ack);
+            return RAFTHIP_OK;
+        }
     }
     (void)hipGetLastError();  // plain host memory reports an error on some runtimes
     if (e->ack_cap < n) {
@@ -612,6 +624,19 @@ int rafthip_destroy(rafthip_engine* e) {
     if (e->h_scalar) (void)hipHostFree(e->h_scalar);
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
+    return RAFTHIP_OK;
+}
+
+int rafthip_host_alloc(void** ptr, uint64_t bytes) {
+    if (!ptr) return fail(RAFTHIP_EINVAL, "ptr is NULL");
+    *ptr = nullptr;
+    if (bytes == 0) return RAFTHIP_OK;
+    HIP_TRY(hipHostMalloc(ptr, (size_t)bytes, hipHostMallocDefault));
+    return RAFTHIP_OK;
+}
+
+int rafthip_host_free(void* ptr) {
+    if (ptr) HIP_TRY(hipHostFree(ptr));
     return RAFTHIP_OK;
 }
 

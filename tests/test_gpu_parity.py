@@ -458,6 +458,46 @@ def test_device_pointers_and_zero_copy_planes(oracle):
         assert np.array_equal(dout.cpu().numpy().view(np.uint64), want)
 
 
+def test_records_in_page_locked_host_memory(oracle):
+    """rafthip_host_alloc: records built in page-locked memory are read by the kernels straight over
+    the link (no staging copy); same results as pageable host memory."""
+    rng = np.random.default_rng(78)
+    S, G, N = 7, 20011, 100000
+    match = rand_match(rng, S, G)
+    recs = np.zeros(N, dtype=raft_amd.ACK_DTYPE)
+    recs["group"] = rng.integers(0, G + 3, size=N)
+    recs["slot"] = rng.integers(0, S, size=N)
+    recs["index"] = rng.integers(0, 1 << 62, size=N, dtype=np.uint64)
+    want = match.copy()
+    skipped = oracle.scatter_acks(want, recs)
+    pin = raft_amd.PinnedArray(N, raft_amd.ACK_DTYPE)
+    try:
+        pin.array[:] = recs
+        with raft_amd.Engine(G, S) as e:
+            e.upload_match(match)
+            e.scatter_acks(pin.array)
+            pin.array["index"] = 0  # the call has returned: the buffer is the caller's again
+            assert np.array_equal(e.read_match(), want)
+            assert e.stats()["acks_rejected"] == skipped > 0
+            msgs = np.zeros(N, dtype=raft_amd.MSG_DTYPE)
+            msgs["group"], msgs["slot"], msgs["type"] = recs["group"], recs["slot"], 4
+            msgs["index"] = recs["index"] + np.uint64(5)
+            pm = raft_amd.PinnedArray(N, raft_amd.MSG_DTYPE)
+            pm.array[:] = msgs
+            active = np.zeros(G, dtype=np.uint8)
+            e.upload_active(active)
+            e.upload_acks(active)
+            e.ingest_msgs(pm.array)
+            last = np.zeros(G, dtype=np.uint64)
+            oracle.step_leader_msgs(want, active, active.copy(), last, msgs)
+            assert np.array_equal(e.read_match(), want) and np.array_equal(e.read_active(), active)
+            pm.free()
+    finally:
+        pin.free()
+    with raft_amd.PinnedArray(0, np.uint8) as empty:
+        assert empty.size == 0
+
+
 def test_two_engines_from_two_threads(oracle):
     """Different engines may be driven from different threads (include/rafthip.h
     conventions); each thread's last-error text is its own."""
