@@ -118,6 +118,8 @@ struct rafthip_engine {
     size_t wire_cap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
     // per-peer replication state (rafthip_progress_config)
+    bool zero_copy_pending = false;  // a kernel on the stream reads the caller's page-locked memory: wait before returning
+
     bool prog = false;
     ProgPlanes pp{};
     u64* first_index = nullptr; // raftLog.firstIndex() per group
@@ -504,10 +506,24 @@ int wire_reserve(rafthip_engine* e, int k, size_t bytes) {
 
 // Input k of the wire path as a device pointer (host memory is copied in).
 int wire_input(rafthip_engine* e, int k, const void* src, size_t bytes, const void** dev) {
-    if (bytes == 0 || is_device_ptr(src)) {
+    if (bytes == 0) {
         *dev = src;
         return RAFTHIP_OK;
     }
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, src) == hipSuccess) {
+        if (attr.type == hipMemoryTypeDevice) {
+            *dev = src;
+            return RAFTHIP_OK;
+        }
+        if (attr.type == hipMemoryTypeHost && attr.devicePointer && !getenv("RAFTHIP_NO_ZERO_COPY")) {
+            *dev = attr.devicePointer;  // page-locked (rafthip_host_alloc): read over the link by the kernel itself
+            e->zero_copy_pending = true;
+            e->stats.bytes_uploaded += bytes;
+            return RAFTHIP_OK;
+        }
+    }
+    (void)hipGetLastError();
     int rc = wire_reserve(e, k, bytes);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(e->wire_buf[k], src, bytes, hipMemcpyHostToDevice, e->stream));
@@ -1082,7 +1098,8 @@ static int wire_run(rafthip_engine* e, const uint8_t* bytes, const uint64_t* off
         }
         if ((rc = progress_passes(e, d_msgs, d_aux, n, d_act))) return rc;
     }
-    bool wait = d_bytes != bytes || d_off != offsets || d_groups != groups;  // caller may reuse its host buffers
+    bool wait = d_bytes != bytes || d_off != offsets || d_groups != groups || e->zero_copy_pending;  // caller may reuse its host buffers
+    e->zero_copy_pending = false;
     if (msgs_host) {
         HIP_TRY(hipMemcpyAsync(out_msgs, d_msgs, (size_t)n * sizeof(Msg), hipMemcpyDeviceToHost, e->stream));
         e->stats.bytes_downloaded += n * sizeof(Msg);
@@ -1339,7 +1356,8 @@ int rafthip_step_progress(rafthip_engine* e, const rafthip_msg* msgs, const uint
         d_act = static_cast<uint8_t*>(e->wire_buf[6]);
     }
     if ((rc = progress_passes(e, static_cast<const Msg*>(d_recs), static_cast<const u64*>(d_aux), n, d_act))) return rc;
-    bool wait = staged || (aux && d_aux != aux);
+    bool wait = staged || (aux && d_aux != aux) || e->zero_copy_pending;
+    e->zero_copy_pending = false;
     if (actions && act_host) {
         HIP_TRY(hipMemcpyAsync(actions, d_act, (size_t)n, hipMemcpyDeviceToHost, e->stream));
         e->stats.bytes_downloaded += n;

@@ -27,7 +27,17 @@ def run_both(oracle, e, state, data, offsets, groups, device_inputs=False):
     e.upload_ids(ids)
     e.upload_term(term)
     e.upload_read_ctx(cw, cl)
-    if device_inputs:
+    if device_inputs == "pinned":  # page-locked host memory: the kernel reads it over the link, no staging copy
+        pins = [raft_amd.PinnedArray(max(len(data), 1), np.uint8), raft_amd.PinnedArray(len(offsets), np.uint64),
+                raft_amd.PinnedArray(len(groups), np.uint32)]
+        pins[0].array[:len(data)] = data
+        pins[1].array[:] = offsets
+        pins[2].array[:] = groups
+        msgs, status, counts = e.ingest_wire(pins[0].array, pins[1].array, pins[2].array, n=len(groups))
+        pins[0].array[:] = 0xFF  # the call has returned: the buffers are the caller's again
+        for p in pins:
+            p.free()
+    elif device_inputs:
         import torch
         keep = [torch.from_numpy(data.copy()).cuda() if len(data) else torch.zeros(1, dtype=torch.uint8, device="cuda"),
                 torch.from_numpy(offsets.view(np.int64).copy()).cuda(),
@@ -44,7 +54,7 @@ def run_both(oracle, e, state, data, offsets, groups, device_inputs=False):
     return want_counts
 
 
-@pytest.mark.parametrize("S,device_inputs", [(3, False), (5, True), (9, False), (16, True), (33, False), (64, False)])
+@pytest.mark.parametrize("S,device_inputs", [(3, False), (5, True), (9, "pinned"), (16, True), (33, False), (64, "pinned")])
 def test_ingest_wire_random_batches(oracle, S, device_inputs):
     rng = np.random.default_rng(1200 + S)
     G, n = 997, 30000
