@@ -23,6 +23,10 @@
  *                            slot s; width rafthip_mask_bytes() = 1/2/4/8 bytes
  *                            for S <= 8/16/32/64
  *   commit   uint64 [G]      last computed quorum commit index
+ *   after rafthip_progress_config: one 32-byte record per Progress row (Next,
+ *                            PendingSnapshot, State, MsgAppFlowPaused, Inflights
+ *                            start/count/bytes) and Inflights rings [entry][S][G];
+ *                            the ABI still moves them as [S][G] planes
  *
  * Conventions.  Every function returns 0 or a negative errno-style code and
  * never throws or aborts (the reference's quorum/tracker functions return no
