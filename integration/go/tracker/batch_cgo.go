@@ -1,0 +1,142 @@
+// Package tracker — batch_cgo.go: the stateful engine of librafthip.so for a
+// multi-raft host, next to the untouched per-group ProgressTracker.  Thin cgo
+// over include/rafthip.h, zero logic: the id -> slot maps, the routing of
+// messages to the engine that owns a group and every send stay with the host
+// (raft_amd/host/tracker_batch.{hpp,cpp} is the same layer in C++, tested in
+// tests/test_host_mirror.py; this file was written to the ABI but not
+// compiled: the build image has no Go toolchain).
+package tracker
+
+/*
+#cgo LDFLAGS: -lrafthip
+#include <rafthip.h>
+*/
+import "C"
+
+import (
+	"fmt"
+	"unsafe"
+)
+
+// BatchEngine holds the quorum-facing state of many groups on one GPU.  Like
+// RawNode it is not safe for concurrent use (rawnode.go:31); one engine per
+// GPU, different engines from different OS-thread-locked goroutines.
+type BatchEngine struct {
+	e      *C.rafthip_engine
+	groups uint64
+	slots  uint32
+}
+
+// Ack is one non-reject MsgAppResp resolved to (group, slot): raft.go:1333,1477.
+type Ack = C.rafthip_ack
+
+// Msg is one response or send-side event: include/rafthip.h, rafthip_msg.
+type Msg = C.rafthip_msg
+
+// CommitPair is a group whose commit index moved: the input of raft.maybeCommit.
+type CommitPair = C.rafthip_commit_pair
+
+func hipErr(rc C.int) error {
+	if rc == 0 {
+		return nil
+	}
+	return fmt.Errorf("rafthip %d: %s", int(rc), C.GoString(C.rafthip_last_error()))
+}
+
+// NewBatchEngine stands where MakeProgressTracker (tracker.go:129-145) stands per
+// group; maxInflight / maxBytes are its arguments (0, 0 leaves the per-peer
+// replication state with the host).
+func NewBatchEngine(device int, groups uint64, slots uint32, maxInflight uint32, maxBytes uint64) (*BatchEngine, error) {
+	cfg := C.rafthip_config{struct_size: C.uint32_t(unsafe.Sizeof(C.rafthip_config{})), device: C.int32_t(device),
+		num_groups: C.uint64_t(groups), num_slots: C.uint32_t(slots)}
+	b := &BatchEngine{groups: groups, slots: slots}
+	if err := hipErr(C.rafthip_create(&cfg, &b.e)); err != nil {
+		return nil, err
+	}
+	if maxInflight > 0 {
+		if err := hipErr(C.rafthip_progress_config(b.e, C.uint32_t(maxInflight), C.uint64_t(maxBytes))); err != nil {
+			b.Close()
+			return nil, err
+		}
+	}
+	return b, nil
+}
+
+func (b *BatchEngine) Close() { C.rafthip_destroy(b.e); b.e = nil }
+
+// TickBuffer is page-locked memory for the records of one tick: the kernels read
+// it over the link themselves (DESIGN.md, "Acks over PCIe").
+func TickBuffer[T any](n int) ([]T, func(), error) {
+	var p unsafe.Pointer
+	var zero T
+	if err := hipErr(C.rafthip_host_alloc(&p, C.uint64_t(uintptr(n)*unsafe.Sizeof(zero)))); err != nil {
+		return nil, nil, err
+	}
+	return unsafe.Slice((*T)(p), n), func() { C.rafthip_host_free(p) }, nil
+}
+
+// SetConfig: raft.switchToConfig (raft.go:1949) for one group; masks are slot bitmasks.
+func (b *BatchEngine) SetConfig(group uint64, incoming, outgoing, learners uint64) error {
+	return hipErr(C.rafthip_upload_config(b.e, C.uint64_t(group), 1, unsafe.Pointer(&incoming), unsafe.Pointer(&outgoing),
+		unsafe.Pointer(&learners))) // little-endian: the low rafthip_mask_bytes() bytes are read
+}
+
+// ScatterAcks: Progress.MaybeUpdate's Match part for a tick's acks (progress.go:168-177).
+func (b *BatchEngine) ScatterAcks(acks []Ack) error {
+	if len(acks) == 0 {
+		return nil
+	}
+	return hipErr(C.rafthip_scatter_acks(b.e, &acks[0], C.uint64_t(len(acks))))
+}
+
+// Step: stepLeader for a tick's responses and send records (raft.go:1333-1586).
+// aux[i] is nextProbeIdx of a rejection / payload bytes of a SENT_APP record;
+// actions[i] tells which send the reference performs next (RAFTHIP_ACT_*).
+func (b *BatchEngine) Step(msgs []Msg, aux []uint64, actions []uint8) error {
+	if len(msgs) == 0 {
+		return nil
+	}
+	return hipErr(C.rafthip_step_progress(b.e, &msgs[0], (*C.uint64_t)(unsafe.Pointer(&aux[0])), C.uint64_t(len(msgs)),
+		(*C.uint8_t)(unsafe.Pointer(&actions[0]))))
+}
+
+// StepWire: the same from serialized raftpb.Message payloads (message i =
+// bytes[offsets[i]:offsets[i+1]] for group groups[i]); status[i] is RAFTHIP_WIRE_*.
+func (b *BatchEngine) StepWire(bytes []byte, offsets []uint64, groups []uint32, status, actions []uint8) error {
+	if len(groups) == 0 {
+		return nil
+	}
+	return hipErr(C.rafthip_step_wire(b.e, (*C.uint8_t)(unsafe.Pointer(&bytes[0])), (*C.uint64_t)(unsafe.Pointer(&offsets[0])),
+		(*C.uint32_t)(unsafe.Pointer(&groups[0])), C.uint64_t(len(groups)), nil, (*C.uint8_t)(unsafe.Pointer(&status[0])), nil,
+		(*C.uint8_t)(unsafe.Pointer(&actions[0]))))
+}
+
+// MaybeCommit: raft.maybeCommit for every group (raft.go:755-758, log.go:447-456);
+// returns the groups whose raftLog.committed moved, sorted by group.
+func (b *BatchEngine) MaybeCommit(pairs []CommitPair) (int, error) {
+	var n C.uint64_t
+	var p *CommitPair
+	if len(pairs) > 0 {
+		p = &pairs[0]
+	}
+	err := hipErr(C.rafthip_commit_advance(b.e, p, C.uint64_t(len(pairs)), &n))
+	if int(n) > len(pairs) {
+		n = C.uint64_t(len(pairs))
+	}
+	return int(n), err
+}
+
+// CheckQuorum: the MsgCheckQuorum step for every group (raft.go:1231-1243);
+// active[g] == 0 means group g steps down.
+func (b *BatchEngine) CheckQuorum(active []uint8) error {
+	if err := hipErr(C.rafthip_check_quorum(b.e)); err != nil {
+		return err
+	}
+	return hipErr(C.rafthip_read_quorum_active(b.e, 0, C.uint64_t(len(active)), (*C.uint8_t)(unsafe.Pointer(&active[0]))))
+}
+
+// HeartbeatCommit: sendHeartbeat's commit per peer (raft.go:669-685), [slot][group].
+func (b *BatchEngine) HeartbeatCommit(dst []uint64) error {
+	return hipErr(C.rafthip_heartbeat_commit(b.e, 0, C.uint64_t(b.groups), (*C.uint64_t)(unsafe.Pointer(&dst[0])),
+		C.uint64_t(b.groups)))
+}
