@@ -290,8 +290,9 @@ __global__ __launch_bounds__(kBlock) void k_progress_apply(const Msg* __restrict
     const Vec<u64, 2> r0 = load_vec<u64, 2>(rw), r1 = load_vec<u64, 2>(rw + 2);
     if ((u32)(r1.v[1] >> 32) != i + 1) return;  // another event of this Progress exchanged later: it owns the list
 
+    // (links above n can only be leftovers of a call that failed between the two passes: treated as the end)
     u32 len = 0;
-    for (u32 j = i + 1; j != 0 && len <= kStepLimit; j = prev[j - 1]) ++len;
+    for (u32 j = i + 1; j != 0 && j <= n && len <= kStepLimit; j = prev[j - 1]) ++len;
     if (len > kStepLimit) {  // all of them stay DEFERRED
         pl.rec[cell].head = 0;
         return;
@@ -317,7 +318,8 @@ __global__ __launch_bounds__(kBlock) void k_progress_apply(const Msg* __restrict
         u32 cur = i + 1;
         if (len > 1) {  // the smallest index above `done`: lists are short, a re-walk beats a sort
             cur = 0xFFFFFFFFu;
-            for (u32 j = i + 1; j != 0; j = prev[j - 1])
+            u32 j = i + 1;
+            for (u32 c = 0; c < len; ++c, j = prev[j - 1])  // exactly the len links counted above
                 if (j > done && j < cur) cur = j;
         }
         const MsgFields f = cur == i + 1 ? own : load_msg(msgs, cur - 1);
