@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""One whole leader-side tick at BASELINE cfg5 scale, inputs resident on the device:
+2^22 groups x (7 voters + 2 learners), 2^24 serialized responses in ->
+  rafthip_step_wire        decode + term gate + Progress lookup + Progress / Inflights stepping
+  rafthip_commit_advance   quorum index + raftLog.maybeCommit's term guard, advanced pairs out
+  rafthip_heartbeat_commit min(Match, committed) per peer
+  rafthip_check_quorum     QuorumActive + RecentActive reset
+Per-stage and whole-tick time from HIP events on the engine's stream; a development tool,
+bench.py stays the headline."""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    import torch
+
+    import golden_util as gu
+    import progress_util as pu
+    import raft_amd
+    import wire_util as wu
+
+    sh = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+    G, S, V, cap = (1 << 22) >> sh, 9, 7, 4
+    N = 4 * G
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(device=dev)
+    rng = np.random.default_rng(0x5EED0009)
+    pl = pu.random_planes(rng, S, G, cap, 0)
+    pl["pstate"][:] = 1  # steady state: every peer replicating, nothing paused
+    ids = np.ascontiguousarray((np.arange(S, dtype=np.uint64)[:, None] + np.uint64(1)) * np.uint64(0x10001)
+                               + rng.integers(0, 1 << 16, size=G, dtype=np.uint64)[None, :] * np.uint64(1 << 20))
+    term = rng.integers(1, 1 << 20, size=G).astype(np.uint64)
+    ctx = rng.integers(1, 1 << 63, size=G, dtype=np.uint64)
+    groups = rng.integers(0, G, size=N).astype(np.uint32)
+    slots = rng.integers(0, S, size=N)
+    data, offsets = wu.encode_responses(rng, ids[slots, groups], term[groups],
+                                        pl["match"][slots, groups] + rng.integers(1, 64, size=N).astype(np.uint64),
+                                        ctx[groups])
+    d_data = torch.from_numpy(data).to(dev)
+    d_off = torch.from_numpy(offsets.view(np.int64)).to(dev)
+    d_grp = torch.from_numpy(groups.view(np.int32)).to(dev)
+    d_status = torch.zeros(N, dtype=torch.uint8, device=dev)
+    d_act = torch.zeros(N, dtype=torch.uint8, device=dev)
+    last = pl["match"].max(axis=0) + np.uint64(128)
+    L = raft_amd.load_library()
+    with raft_amd.Engine(G, S, stream=stream.cuda_stream) as e:
+        e.set_uniform_config(V)
+        e.progress_config(cap, 0)
+        e.upload_ids(ids)
+        e.upload_term(term)
+        e.upload_read_ctx(ctx, np.full(G, 8, dtype=np.uint8))
+        e.upload_self(np.ones(G, dtype=np.uint16))
+
+        def reset():
+            e.upload_match(pl["match"])
+            e.upload_progress(pl["pstate"], pl["next"], pl["pending"])
+            e.upload_commit(np.zeros(G, dtype=np.uint64))
+            e.upload_term_range(np.zeros(G, dtype=np.uint64), last)
+            e.upload_active(np.ones(G, dtype=np.uint16))
+            e.upload_acks(np.zeros(G, dtype=np.uint16))
+
+        stages = [
+            ("step_wire", lambda: L.rafthip_step_wire(e._h, d_data.data_ptr(), d_off.data_ptr(), d_grp.data_ptr(), N, None,
+                                                     d_status.data_ptr(), None, d_act.data_ptr())),
+            ("commit_advance", lambda: e.commit_advance(max_pairs=0)),
+            ("heartbeat_commit", lambda: e.heartbeat_commit(download=False)),
+            ("check_quorum", lambda: e.check_quorum()),
+        ]
+        times = {k: [] for k, _ in stages}
+        advanced = 0
+        with torch.cuda.stream(stream):
+            for it in range(4):
+                reset()
+                torch.cuda.synchronize()
+                for name, fn in stages:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(stream)
+                    r = fn()
+                    e1.record(stream)
+                    e1.synchronize()
+                    if it:
+                        times[name].append(e0.elapsed_time(e1))
+                    if name == "commit_advance":
+                        advanced = r[1]
+        out = {k: round(float(np.median(v)), 3) for k, v in times.items()}
+        tick = sum(out.values())
+        print(json.dumps({"groups": G, "slots": S, "messages": N, "bytes_per_message": round(len(data) / N, 1),
+                          "stage_ms": out, "tick_ms": round(tick, 3), "messages_per_s": N / tick * 1e3,
+                          "groups_advanced": int(advanced), "applied": int((d_status == 0).sum().item()),
+                          "updated": int(((d_act & 2) != 0).sum().item())}))
+
+
+if __name__ == "__main__":
+    main()
