@@ -10,8 +10,8 @@
 #include <new>
 
 #include "kernels.h"
-#include "wire.h"
 #include "progress.h"
+#include "wire.h"
 #include "rafthip.h"
 
 using namespace rafthip;
@@ -1015,7 +1015,8 @@ int rafthip_upload_read_ctx(rafthip_engine* e, uint64_t first, uint64_t count, c
     return RAFTHIP_OK;
 }
 
-static int progress_passes(rafthip_engine* e, const Msg* d_msgs, const u64* d_aux, uint64_t n, uint8_t* d_act);
+static int progress_passes(rafthip_engine* e, const Msg* d_msgs, const u64* d_aux, uint64_t n, uint8_t* d_act,
+                           bool linked);
 
 // Decode + classify n serialized messages; actions == NULL: step them as K7 does
 // (rafthip_ingest_wire); else hand the decoded records to the Progress stepper
@@ -1077,6 +1078,17 @@ static int wire_run(rafthip_engine* e, const uint8_t* bytes, const uint64_t* off
             d_status = out_status;
         }
     }
+    const bool act_host = to_progress && (!actions || !is_device_ptr(actions));
+    uint8_t* d_act = actions;
+    u32* d_prev = nullptr;
+    if (to_progress) {  // the decode kernel also links each event into its Progress's list (k_progress_link's work)
+        if (act_host) {
+            if ((rc = wire_reserve(e, 6, (size_t)n))) return rc;
+            d_act = static_cast<uint8_t*>(e->wire_buf[6]);
+        }
+        if ((rc = wire_reserve(e, 7, (size_t)n * sizeof(u32)))) return rc;
+        d_prev = static_cast<u32*>(e->wire_buf[7]);
+    }
     HIP_TRY(hipMemsetAsync(e->d_wire_counts, 0, RAFTHIP_WIRE_STATUSES * sizeof(u64), e->stream));
     for (u64 off = 0; off < n; off += kMaxRecordsPerLaunch) {
         const u64 m = n - off < kMaxRecordsPerLaunch ? n - off : kMaxRecordsPerLaunch;
@@ -1086,18 +1098,10 @@ static int wire_run(rafthip_engine* e, const uint8_t* bytes, const uint64_t* off
                            static_cast<const u32*>(d_groups) + off, m, e->G, e->S, static_cast<const u64*>(e->wire_hdr),
                            wire_hdr_words(e->S), e->match, e->stride, e->active, e->acks, e->mbytes,
                            d_msgs ? d_msgs + off : nullptr, d_status ? d_status + off : nullptr, e->d_wire_counts,
-                           d_aux ? d_aux + off : nullptr);
+                           d_aux ? d_aux + off : nullptr, e->pp.rec, d_prev, d_act, (u32)off);
         HIP_TRY(hipGetLastError());
     }
-    const bool act_host = to_progress && (!actions || !is_device_ptr(actions));
-    uint8_t* d_act = actions;
-    if (to_progress) {
-        if (act_host) {
-            if ((rc = wire_reserve(e, 6, (size_t)n))) return rc;
-            d_act = static_cast<uint8_t*>(e->wire_buf[6]);
-        }
-        if ((rc = progress_passes(e, d_msgs, d_aux, n, d_act))) return rc;
-    }
+    if (to_progress && (rc = progress_passes(e, d_msgs, d_aux, n, d_act, true))) return rc;
     bool wait = d_bytes != bytes || d_off != offsets || d_groups != groups || e->zero_copy_pending;  // caller may reuse its host buffers
     e->zero_copy_pending = false;
     if (msgs_host) {
@@ -1314,7 +1318,8 @@ int rafthip_upload_first_index(rafthip_engine* e, uint64_t first, uint64_t count
 }
 
 // The link and apply passes over n device-resident records (d_act: device, n bytes).
-static int progress_passes(rafthip_engine* e, const Msg* d_msgs, const u64* d_aux, uint64_t n, uint8_t* d_act) {
+static int progress_passes(rafthip_engine* e, const Msg* d_msgs, const u64* d_aux, uint64_t n, uint8_t* d_act,
+                           bool linked) {
     int rc;
     const size_t mb = (size_t)e->stride * e->mbytes;
     if ((rc = ensure(e, e->active, mb))) return rc;
@@ -1322,9 +1327,11 @@ static int progress_passes(rafthip_engine* e, const Msg* d_msgs, const u64* d_au
     if ((rc = wire_reserve(e, 7, (size_t)n * sizeof(u32)))) return rc;
     u32* prev = static_cast<u32*>(e->wire_buf[7]);
     const u32 blocks = (u32)((n + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(k_progress_link, dim3(blocks), dim3(kBlock), 0, e->stream, d_msgs, (u32)n, e->G, e->S,
-                       e->stride, e->pp.rec, prev, e->term_last, d_act);
-    HIP_TRY(hipGetLastError());
+    if (!linked) {
+        hipLaunchKernelGGL(k_progress_link, dim3(blocks), dim3(kBlock), 0, e->stream, d_msgs, (u32)n, e->G, e->S,
+                           e->stride, e->pp.rec, prev, e->term_last, d_act);
+        HIP_TRY(hipGetLastError());
+    }
     e->pp.match = e->match;
     hipLaunchKernelGGL(k_progress_apply, dim3(blocks), dim3(kBlock), 0, e->stream, d_msgs, d_aux, (u32)n, e->G, e->S,
                        e->pp, static_cast<const u32*>(prev), e->active, e->acks, e->mbytes,
@@ -1355,7 +1362,8 @@ int rafthip_step_progress(rafthip_engine* e, const rafthip_msg* msgs, const uint
         if ((rc = wire_reserve(e, 6, (size_t)n))) return rc;
         d_act = static_cast<uint8_t*>(e->wire_buf[6]);
     }
-    if ((rc = progress_passes(e, static_cast<const Msg*>(d_recs), static_cast<const u64*>(d_aux), n, d_act))) return rc;
+    if ((rc = progress_passes(e, static_cast<const Msg*>(d_recs), static_cast<const u64*>(d_aux), n, d_act, false)))
+        return rc;
     bool wait = staged || (aux && d_aux != aux) || e->zero_copy_pending;
     e->zero_copy_pending = false;
     if (actions && act_host) {

@@ -10,6 +10,7 @@
 // not fit is parsed straight from global memory.
 #pragma once
 #include "kernels.h"
+#include "progress.h"
 
 namespace rafthip {
 
@@ -177,7 +178,9 @@ __global__ __launch_bounds__(kWireBlock) void k_ingest_wire(
     u64* __restrict__ match, u64 stride,
     void* __restrict__ active, void* __restrict__ acks, int mbytes, Msg* __restrict__ out_msgs,
     uint8_t* __restrict__ out_status, u64* __restrict__ counters /* [kWireStatuses] */,
-    u64* __restrict__ out_aux /* non-NULL: decode only, the records go on to the Progress stepper */) {
+    u64* __restrict__ out_aux /* non-NULL: decode only, the records go on to the Progress stepper */,
+    ProgRec* __restrict__ rec, u32* __restrict__ prev, uint8_t* __restrict__ actions, u32 index_base
+    /* with out_aux: k_progress_link's work for message i, list index index_base + i */) {
     __shared__ __align__(16) uint8_t sm[kWireLdsBytes + 32];
     __shared__ u32 hist[kWireStatuses];
     const u64 i0 = (u64)blockIdx.x * kWireBlock;
@@ -291,7 +294,16 @@ __global__ __launch_bounds__(kWireBlock) void k_ingest_wire(
             store_vec<u64, 2>(reinterpret_cast<u64*>(out_msgs + i), o);
         }
         if (out_status) out_status[i] = status;
-        if (out_aux) out_aux[i] = aux;
+        if (out_aux) {
+            out_aux[i] = aux;
+            if (slot != kWireNoSlot) {  // applied or needs-log: an event of Progress (slot, group)
+                const u32 li = index_base + (u32)i;
+                prev[li] = atomicExch(&rec[(u64)slot * stride + group].head, li + 1);
+                actions[li] = kActDeferred;
+            } else {
+                actions[index_base + (u32)i] = kActDropped;
+            }
+        }
         atomicAdd(&hist[status], 1u);
     }
     __syncthreads();
