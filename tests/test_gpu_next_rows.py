@@ -292,3 +292,18 @@ def test_scenario_fixtures_on_the_gpu():
                 e.ingest_msgs(msgs)
                 e.ack_quorum()
                 assert int(e.read_ack_quorum()[0]) == names[st["result"]], (seq["src"], st)
+
+
+def test_heartbeat_commit_cases_on_the_gpu():
+    import json
+    import os
+    with open(os.path.join(gu.HERE, "golden", "scenarios.json")) as fh:
+        cases = json.load(fh)["heartbeat_commit_cases"]
+    for c in cases:
+        n = len(c["ids"])
+        with raft_amd.Engine(1, n) as e:
+            e.upload_match(np.array(c["match"], dtype=np.uint64).reshape(n, 1))
+            e.upload_commit(np.array([c["committed"]], dtype=np.uint64))
+            got = e.heartbeat_commit()
+            for peer, want in c["want"].items():
+                assert int(got[c["ids"].index(int(peer)), 0]) == want, c["src"]

@@ -133,3 +133,16 @@ def test_scenario_fixtures_on_the_oracle(oracle):
         for st in seq["steps"]:
             acks = {i: True for i in st["acks"]}
             assert oracle.majority_vote_result(seq["voters"], acks) == NAMES[st["result"]], (seq["src"], st)
+
+
+def test_heartbeat_commit_cases(oracle):
+    """sendHeartbeat's Commit (raft.go:669-685) against what the reference's interaction tests print."""
+    import json
+    import os
+    with open(os.path.join(gu.HERE, "golden", "scenarios.json")) as fh:
+        cases = json.load(fh)["heartbeat_commit_cases"]
+    for c in cases:
+        match = np.array(c["match"], dtype=np.uint64).reshape(-1, 1)
+        got = oracle.batch_heartbeat_commit(match, np.array([c["committed"]], dtype=np.uint64))
+        for peer, want in c["want"].items():
+            assert int(got[c["ids"].index(int(peer)), 0]) == want, c["src"]
