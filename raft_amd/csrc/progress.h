@@ -65,7 +65,7 @@ struct alignas(32) ProgRec {
 };
 constexpr u32 kMaxInflight = 16383;
 __host__ __device__ __forceinline__ u32 rec_meta(u32 start, u32 count, u32 pstate) {
-    return start | (count << 14) | (pstate << 29);
+    return (start & 0x3FFFu) | ((count & 0x7FFFu) << 14) | (pstate << 29);
 }
 
 struct ProgPlanes {
