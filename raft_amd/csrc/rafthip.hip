@@ -114,8 +114,8 @@ struct rafthip_engine {
     bool have_ids = false, have_term = false;
     u64* d_wire_counts = nullptr;  // [RAFTHIP_WIRE_STATUSES]
     // growable staging: wire bytes, offsets, groups, out msgs, out status; progress aux, actions, prev links
-    void* wire_buf[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    size_t wire_cap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    void* stage_buf[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t stage_cap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
     // per-peer replication state (rafthip_progress_config)
     bool zero_copy_pending = false;  // a kernel on the stream reads the caller's page-locked memory: wait before returning
@@ -490,22 +490,22 @@ bool is_device_ptr(const void* p) {
     return false;
 }
 
-// Growable device staging buffer k of the wire path.
-int wire_reserve(rafthip_engine* e, int k, size_t bytes) {
-    if (e->wire_cap[k] >= bytes) return RAFTHIP_OK;
-    if (e->wire_buf[k]) {
+// Growable device staging buffer k (wire bytes / offsets / groups / records / statuses, aux words, action bytes, list links).
+int stage_reserve(rafthip_engine* e, int k, size_t bytes) {
+    if (e->stage_cap[k] >= bytes) return RAFTHIP_OK;
+    if (e->stage_buf[k]) {
         HIP_TRY(hipStreamSynchronize(e->stream));
-        HIP_TRY(hipFree(e->wire_buf[k]));
-        e->wire_buf[k] = nullptr;
-        e->wire_cap[k] = 0;
+        HIP_TRY(hipFree(e->stage_buf[k]));
+        e->stage_buf[k] = nullptr;
+        e->stage_cap[k] = 0;
     }
-    HIP_TRY(hipMalloc(&e->wire_buf[k], bytes));
-    e->wire_cap[k] = bytes;
+    HIP_TRY(hipMalloc(&e->stage_buf[k], bytes));
+    e->stage_cap[k] = bytes;
     return RAFTHIP_OK;
 }
 
-// Input k of the wire path as a device pointer (host memory is copied in).
-int wire_input(rafthip_engine* e, int k, const void* src, size_t bytes, const void** dev) {
+// Input k as a device-visible pointer: device memory and page-locked host memory as they are, pageable host memory copied in.
+int stage_input(rafthip_engine* e, int k, const void* src, size_t bytes, const void** dev) {
     if (bytes == 0) {
         *dev = src;
         return RAFTHIP_OK;
@@ -524,11 +524,11 @@ int wire_input(rafthip_engine* e, int k, const void* src, size_t bytes, const vo
         }
     }
     (void)hipGetLastError();
-    int rc = wire_reserve(e, k, bytes);
+    int rc = stage_reserve(e, k, bytes);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(e->wire_buf[k], src, bytes, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->stage_buf[k], src, bytes, hipMemcpyHostToDevice, e->stream));
     e->stats.bytes_uploaded += bytes;
-    *dev = e->wire_buf[k];
+    *dev = e->stage_buf[k];
     return RAFTHIP_OK;
 }
 
@@ -632,8 +632,8 @@ int rafthip_destroy(rafthip_engine* e) {
                     e->ack_result, e->stage,   e->packed,       e->counts,   e->offsets,  e->ack_buf,
                     e->d_rejected, e->self_mask, e->term_first, e->term_last, e->hb_commit, e->in_term,
                     e->wire_hdr, e->d_wire_counts,
-                    e->wire_buf[0], e->wire_buf[1], e->wire_buf[2], e->wire_buf[3], e->wire_buf[4],
-                    e->wire_buf[5], e->wire_buf[6], e->wire_buf[7], e->pp.rec, e->pp.ring_index, e->pp.ring_bytes,
+                    e->stage_buf[0], e->stage_buf[1], e->stage_buf[2], e->stage_buf[3], e->stage_buf[4],
+                    e->stage_buf[5], e->stage_buf[6], e->stage_buf[7], e->pp.rec, e->pp.ring_index, e->pp.ring_bytes,
                     e->first_index};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
@@ -866,9 +866,9 @@ int rafthip_merge_acks(rafthip_engine* e, uint64_t first, uint64_t count, const 
     bool staged = false;
     if (!is_device_ptr(acks)) {  // host plane: staged through the engine's growable buffer, packed to pitch = count
         d_stride = (count + 1) & ~1ull;
-        if ((rc = wire_reserve(e, 5, (size_t)d_stride * e->S * sizeof(u64)))) return rc;
-        if ((rc = copy_rows(e, e->wire_buf[5], d_stride * 8, acks, src_stride * 8, count * 8, e->S))) return rc;
-        d_acks = static_cast<const u64*>(e->wire_buf[5]);
+        if ((rc = stage_reserve(e, 5, (size_t)d_stride * e->S * sizeof(u64)))) return rc;
+        if ((rc = copy_rows(e, e->stage_buf[5], d_stride * 8, acks, src_stride * 8, count * 8, e->S))) return rc;
+        d_acks = static_cast<const u64*>(e->stage_buf[5]);
         e->stats.bytes_uploaded += count * 8 * e->S;
         staged = true;
     }
@@ -1049,12 +1049,12 @@ static int wire_run(rafthip_engine* e, const uint8_t* bytes, const uint64_t* off
         d_off = offsets;
     } else {
         nbytes = offsets[n];
-        if ((rc = wire_input(e, 1, offsets, (size_t)(n + 1) * sizeof(u64), &d_off))) return rc;
+        if ((rc = stage_input(e, 1, offsets, (size_t)(n + 1) * sizeof(u64), &d_off))) return rc;
     }
     if (nbytes > 0 && !bytes) return fail(RAFTHIP_EINVAL, "bytes is NULL");
     const void *d_bytes = nullptr, *d_groups = nullptr;
-    if ((rc = wire_input(e, 0, bytes, (size_t)nbytes, &d_bytes))) return rc;
-    if ((rc = wire_input(e, 2, groups, (size_t)n * sizeof(u32), &d_groups))) return rc;
+    if ((rc = stage_input(e, 0, bytes, (size_t)nbytes, &d_bytes))) return rc;
+    if ((rc = stage_input(e, 2, groups, (size_t)n * sizeof(u32), &d_groups))) return rc;
     Msg* d_msgs = nullptr;
     uint8_t* d_status = nullptr;
     const bool msgs_host = out_msgs && !is_device_ptr(out_msgs);
@@ -1062,18 +1062,18 @@ static int wire_run(rafthip_engine* e, const uint8_t* bytes, const uint64_t* off
     if (out_msgs && !msgs_host) {
         d_msgs = reinterpret_cast<Msg*>(out_msgs);
     } else if (out_msgs || to_progress) {
-        if ((rc = wire_reserve(e, 3, (size_t)n * sizeof(Msg)))) return rc;
-        d_msgs = static_cast<Msg*>(e->wire_buf[3]);
+        if ((rc = stage_reserve(e, 3, (size_t)n * sizeof(Msg)))) return rc;
+        d_msgs = static_cast<Msg*>(e->stage_buf[3]);
     }
     u64* d_aux = nullptr;
     if (to_progress) {
-        if ((rc = wire_reserve(e, 5, (size_t)n * sizeof(u64)))) return rc;
-        d_aux = static_cast<u64*>(e->wire_buf[5]);
+        if ((rc = stage_reserve(e, 5, (size_t)n * sizeof(u64)))) return rc;
+        d_aux = static_cast<u64*>(e->stage_buf[5]);
     }
     if (out_status) {
         if (status_host) {
-            if ((rc = wire_reserve(e, 4, (size_t)n))) return rc;
-            d_status = static_cast<uint8_t*>(e->wire_buf[4]);
+            if ((rc = stage_reserve(e, 4, (size_t)n))) return rc;
+            d_status = static_cast<uint8_t*>(e->stage_buf[4]);
         } else {
             d_status = out_status;
         }
@@ -1083,11 +1083,11 @@ static int wire_run(rafthip_engine* e, const uint8_t* bytes, const uint64_t* off
     u32* d_prev = nullptr;
     if (to_progress) {  // the decode kernel also links each event into its Progress's list (k_progress_link's work)
         if (act_host) {
-            if ((rc = wire_reserve(e, 6, (size_t)n))) return rc;
-            d_act = static_cast<uint8_t*>(e->wire_buf[6]);
+            if ((rc = stage_reserve(e, 6, (size_t)n))) return rc;
+            d_act = static_cast<uint8_t*>(e->stage_buf[6]);
         }
-        if ((rc = wire_reserve(e, 7, (size_t)n * sizeof(u32)))) return rc;
-        d_prev = static_cast<u32*>(e->wire_buf[7]);
+        if ((rc = stage_reserve(e, 7, (size_t)n * sizeof(u32)))) return rc;
+        d_prev = static_cast<u32*>(e->stage_buf[7]);
     }
     HIP_TRY(hipMemsetAsync(e->d_wire_counts, 0, RAFTHIP_WIRE_STATUSES * sizeof(u64), e->stream));
     for (u64 off = 0; off < n; off += kMaxRecordsPerLaunch) {
@@ -1324,8 +1324,8 @@ static int progress_passes(rafthip_engine* e, const Msg* d_msgs, const u64* d_au
     const size_t mb = (size_t)e->stride * e->mbytes;
     if ((rc = ensure(e, e->active, mb))) return rc;
     if ((rc = ensure(e, e->acks, mb))) return rc;
-    if ((rc = wire_reserve(e, 7, (size_t)n * sizeof(u32)))) return rc;
-    u32* prev = static_cast<u32*>(e->wire_buf[7]);
+    if ((rc = stage_reserve(e, 7, (size_t)n * sizeof(u32)))) return rc;
+    u32* prev = static_cast<u32*>(e->stage_buf[7]);
     const u32 blocks = (u32)((n + kBlock - 1) / kBlock);
     if (!linked) {
         hipLaunchKernelGGL(k_progress_link, dim3(blocks), dim3(kBlock), 0, e->stream, d_msgs, (u32)n, e->G, e->S,
@@ -1355,12 +1355,12 @@ int rafthip_step_progress(rafthip_engine* e, const rafthip_msg* msgs, const uint
     bool staged = false;
     if ((rc = stage_records(e, msgs, n, &d_recs, &staged))) return rc;
     const void* d_aux = nullptr;
-    if (aux && (rc = wire_input(e, 5, aux, (size_t)n * sizeof(u64), &d_aux))) return rc;
+    if (aux && (rc = stage_input(e, 5, aux, (size_t)n * sizeof(u64), &d_aux))) return rc;
     const bool act_host = !actions || !is_device_ptr(actions);
     uint8_t* d_act = actions;
     if (act_host) {
-        if ((rc = wire_reserve(e, 6, (size_t)n))) return rc;
-        d_act = static_cast<uint8_t*>(e->wire_buf[6]);
+        if ((rc = stage_reserve(e, 6, (size_t)n))) return rc;
+        d_act = static_cast<uint8_t*>(e->stage_buf[6]);
     }
     if ((rc = progress_passes(e, static_cast<const Msg*>(d_recs), static_cast<const u64*>(d_aux), n, d_act, false)))
         return rc;
