@@ -190,6 +190,8 @@ int rafthip_upload_votes(rafthip_engine *e, uint64_t first, uint64_t count, cons
                          uint64_t src_stride);
 /* ProgressTracker.ResetVotes — tracker/tracker.go:254-256. */
 int rafthip_reset_votes(rafthip_engine *e, uint64_t first, uint64_t count);
+/* The vote cells as the engine holds them (after rafthip_record_votes). */
+int rafthip_read_votes(rafthip_engine *e, uint64_t first, uint64_t count, uint8_t *dst, uint64_t dst_stride);
 
 /* Progress.RecentActive bits (tracker/progress.go:72; set at raft.go:1337,1528). */
 int rafthip_upload_active(rafthip_engine *e, uint64_t first, uint64_t count, const void *src);
@@ -248,6 +250,18 @@ int rafthip_merge_acks(rafthip_engine *e, uint64_t first, uint64_t count, const 
  * in stats.msgs_ignored.  The Progress FSM side effects (Probe/Replicate,
  * Inflights, MaybeDecrTo on Reject) stay with the host. */
 int rafthip_ingest_msgs(rafthip_engine *e, const rafthip_msg *msgs, uint64_t n);
+
+/* ProgressTracker.RecordVote for a batch of vote responses — tracker/tracker.go:260-265
+ * via raft.poll (raft.go:1041-1049): records of type MsgVoteResp (6) or
+ * MsgPreVoteResp (18) (the host submits the kind its campaign counts,
+ * raft.go:1647-1650), vote = !reject; the FIRST vote of a (group, slot) sticks —
+ * first in stream order, also between two records of one batch, also against a
+ * vote recorded before the batch (rafthip_upload_votes, earlier calls).  Records
+ * of other types or without a Progress row are dropped (stats.msgs_dropped).
+ * Followed by rafthip_tally_votes. */
+#define RAFTHIP_MSG_VOTE_RESP 6
+#define RAFTHIP_MSG_PRE_VOTE_RESP 18
+int rafthip_record_votes(rafthip_engine *e, const rafthip_msg *msgs, uint64_t n);
 
 /* ---- wire ingest: the same step from serialized raftpb.Message bytes ------ */
 

@@ -104,6 +104,8 @@ def lib():
         L.oracle_step_progress.restype = None
         L.oracle_step_progress.argtypes = [C.c_uint64, C.c_int, C.c_uint64] + [vp] * 8 + [C.c_int, C.c_uint64, vp, vp,
                                            C.c_int, vp, vp, vp, vp, C.c_uint64, C.c_uint32, vp]
+        L.oracle_record_votes.restype = C.c_uint64
+        L.oracle_record_votes.argtypes = [C.c_uint64, C.c_int, vp, C.c_uint64, vp, C.c_uint64]
         L.oracle_decode_wire_msgs.restype = None
         L.oracle_decode_wire_msgs.argtypes = [C.c_uint64, C.c_int, vp, C.c_uint64, vp, vp, vp, vp, C.c_uint64, vp, vp,
                                               C.c_uint64, vp, vp, vp, vp]
@@ -356,6 +358,14 @@ def step_wire_msgs(match, active, acks, ids, term, read_ctx, read_ctx_len, data,
                                 _vp(data) if len(data) else None, len(data), _vp(offsets), _vp(groups), n,
                                 _vp(out_msgs), _vp(out_status), _vp(counts))
     return out_msgs, out_status, counts
+
+
+def record_votes(votes, msgs):
+    """RecordVote for a stream of vote responses in order (first vote of a cell sticks); mutates votes [S][G]."""
+    votes = _chk(votes, np.uint8)
+    S, G = votes.shape
+    msgs = _chk(msgs, MSG_DTYPE)
+    return int(lib().oracle_record_votes(G, S, _vp(votes), votes.strides[0], _vp(msgs), len(msgs)))
 
 
 def decode_wire_msgs(ids, term, read_ctx, read_ctx_len, data, offsets, groups):

@@ -691,6 +691,28 @@ ORACLE_API void oracle_step_leader_msgs(uint64_t G, int nslots, uint64_t *match,
     }
 }
 
+/*
+ * tracker/tracker.go:260-265 — RecordVote for a stream of vote responses, one at
+ * a time in order: `_, ok := p.Votes[id]; if !ok { p.Votes[id] = v }`.  votes is
+ * the [slot][stride] cell plane (0 none, 1 rejected, 2 granted); records of type
+ * MsgVoteResp (6) / MsgPreVoteResp (18) count, vote = !reject.  Returns the
+ * number of records dropped (other types, no Progress row).
+ */
+ORACLE_API uint64_t oracle_record_votes(uint64_t G, int nslots, uint8_t *votes, uint64_t stride,
+                                        const oracle_msg *msgs, uint64_t n) {
+    uint64_t dropped = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        const oracle_msg *m = &msgs[i];
+        if ((m->type != 6 && m->type != 18) || m->group >= G || m->slot >= nslots) {
+            dropped++;
+            continue;
+        }
+        uint8_t *cell = &votes[(uint64_t)m->slot * stride + m->group];
+        if (*cell == 0) *cell = m->reject ? 1 : 2;
+    }
+    return dropped;
+}
+
 /* ------------------------------------------------------------------------ */
 /* Serialized raftpb.Message -> stepLeader bookkeeping.                       */
 /* ------------------------------------------------------------------------ */

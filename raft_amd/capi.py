@@ -43,7 +43,9 @@ SYMBOLS = [
     "rafthip_progress_config", "rafthip_upload_progress", "rafthip_read_progress", "rafthip_upload_inflights",
     "rafthip_read_inflights", "rafthip_upload_first_index", "rafthip_step_progress", "rafthip_step_wire",
     "rafthip_merge_acks", "rafthip_host_alloc", "rafthip_host_free",
+    "rafthip_record_votes", "rafthip_read_votes",
 ]
+MSG_VOTE_RESP, MSG_PRE_VOTE_RESP = 6, 18
 
 STATE_PROBE, STATE_REPLICATE, STATE_SNAPSHOT, PROGRESS_PAUSED = 0, 1, 2, 4
 MSG_UNREACHABLE, MSG_SNAP_STATUS, MSG_SENT_APP, MSG_SENT_SNAP = 10, 11, 0xF1, 0xF2
@@ -167,6 +169,8 @@ def load_library():
         "rafthip_step_progress": (i32, [vp, vp, vp, u64, vp]),
         "rafthip_step_wire": (i32, [vp, vp, vp, vp, u64, vp, vp, vp, vp]),
         "rafthip_merge_acks": (i32, [vp, u64, u64, vp, u64]),
+        "rafthip_record_votes": (i32, [vp, vp, u64]),
+        "rafthip_read_votes": (i32, [vp, u64, u64, vp, u64]),
         "rafthip_host_alloc": (i32, [C.POINTER(vp), u64]),
         "rafthip_host_free": (i32, [vp]),
     }
@@ -318,6 +322,17 @@ class Engine:
         """acks: u64 [S][count] plane (numpy, torch or raw device pointer with stride), 0 = no ack."""
         first, count = self._range(first, count)
         _check(self._L.rafthip_merge_acks(self._h, first, count, _ptr(acks), count if stride is None else stride))
+
+    def read_votes(self, first=0, count=None):
+        first, count = self._range(first, count)
+        out = np.empty((self.S, count), dtype=np.uint8)
+        _check(self._L.rafthip_read_votes(self._h, first, count, _ptr(out), count))
+        return out
+
+    def record_votes(self, msgs, n=None):
+        if n is None:
+            n = len(msgs)
+        _check(self._L.rafthip_record_votes(self._h, _ptr(msgs), n))
 
     def commit(self):
         _check(self._L.rafthip_commit(self._h))

@@ -694,6 +694,54 @@ __global__ __launch_bounds__(kBlock) void k_merge_acks(u64* __restrict__ match, 
 }
 
 // ---------------------------------------------------------------------------
+// K5v — ProgressTracker.RecordVote for a stream of vote responses:
+// "the first vote of an id sticks" (tracker/tracker.go:260-265).  First means
+// first in stream order, and two records of one batch may disagree (a duplicate
+// from a confused peer), so the order must not depend on which lane runs first:
+//   pass 1  every record raises first[cell] to ~i with a 32-bit atomicMax — the
+//           largest ~i is the smallest stream index i, whatever the order
+//   pass 2  the record that finds its own ~i there writes its vote, if the cell
+//           held none before the batch (one writer per cell: plain byte store)
+//   pass 3  every record clears first[cell] again
+// ---------------------------------------------------------------------------
+constexpr uint8_t kMsgVoteResp = 6, kMsgPreVoteResp = 18;  // raftpb/raft.proto:48,60
+__device__ __forceinline__ bool vote_record(const Msg* msgs, u64 i, u64 G, u32 S, u32& group, u32& slot, bool& reject) {
+    const Vec<u64, 2> raw = load_vec<u64, 2>(reinterpret_cast<const u64*>(msgs + i));
+    group = (u32)raw.v[0];
+    slot = (u32)(raw.v[0] >> 32) & 0xFFu;
+    const u32 type = (u32)(raw.v[0] >> 40) & 0xFFu;
+    reject = ((raw.v[0] >> 48) & 0xFFu) != 0;
+    return (type == kMsgVoteResp || type == kMsgPreVoteResp) && (u64)group < G && slot < S;
+}
+template <int PASS>
+__global__ __launch_bounds__(kBlock) void k_record_votes(uint8_t* __restrict__ votes, u32* __restrict__ first,
+                                                         u64 stride, u64 G, u32 S, const Msg* __restrict__ msgs,
+                                                         u32 n, u64* __restrict__ dropped) {
+    const u32 i = blockIdx.x * kBlock + threadIdx.x;
+    bool bad = false;
+    if (i < n) {
+        u32 group, slot;
+        bool reject;
+        if (vote_record(msgs, i, G, S, group, slot, reject)) {
+            const u64 cell = (u64)slot * stride + group;
+            if (PASS == 1) {
+                atomicMax(first + cell, ~i);
+            } else if (PASS == 2) {
+                if (first[cell] == ~i && votes[cell] == 0) votes[cell] = reject ? 1 : 2;
+            } else {
+                first[cell] = 0;
+            }
+        } else {
+            bad = PASS == 1;
+        }
+    }
+    if (PASS == 1) {
+        const u64 b = __ballot(bad);
+        if (b != 0 && (threadIdx.x & 63) == 0) atomicAdd(dropped, (u64)__popcll(b));
+    }
+}
+
+// ---------------------------------------------------------------------------
 // K7 — the leader's per-message bookkeeping for a stream of responses that the
 // host has resolved to (group, slot): stepLeader, raft.go:1327-1561.
 //   MsgAppResp        RecentActive = true (:1337); if !Reject: MaybeUpdate(Index) (:1477)

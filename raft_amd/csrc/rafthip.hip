@@ -81,6 +81,7 @@ struct rafthip_engine {
     u64* match = nullptr;
     u64* commit = nullptr;
     uint8_t* votes = nullptr;
+    u32* vote_first = nullptr;  // [S][stride] scratch of rafthip_record_votes, zero between calls
     void* active = nullptr;
     void* acks = nullptr;
     void* self_mask = nullptr;
@@ -634,7 +635,7 @@ int rafthip_destroy(rafthip_engine* e) {
                     e->wire_hdr, e->d_wire_counts,
                     e->stage_buf[0], e->stage_buf[1], e->stage_buf[2], e->stage_buf[3], e->stage_buf[4],
                     e->stage_buf[5], e->stage_buf[6], e->stage_buf[7], e->pp.rec, e->pp.ring_index, e->pp.ring_bytes,
-                    e->first_index};
+                    e->first_index, e->vote_first};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (e->h_scalar) (void)hipHostFree(e->h_scalar);
@@ -799,6 +800,19 @@ int rafthip_upload_votes(rafthip_engine* e, uint64_t first, uint64_t count, cons
     return RAFTHIP_OK;
 }
 
+int rafthip_read_votes(rafthip_engine* e, uint64_t first, uint64_t count, uint8_t* dst, uint64_t dst_stride) {
+    int rc = check_range(e, first, count);
+    if (rc) return rc;
+    if (!dst) return fail(RAFTHIP_EINVAL, "dst is NULL");
+    if (dst_stride < count) return fail(RAFTHIP_EINVAL, "dst_stride %llu < count %llu", (u64)dst_stride, (u64)count);
+    DeviceGuard guard(e->device);
+    if ((rc = ensure(e, e->votes, (size_t)e->S * e->stride))) return rc;
+    if ((rc = copy_rows(e, dst, dst_stride, e->votes + first, e->stride, count, e->S))) return rc;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    e->stats.bytes_downloaded += count * e->S;
+    return RAFTHIP_OK;
+}
+
 int rafthip_reset_votes(rafthip_engine* e, uint64_t first, uint64_t count) {
     int rc = check_range(e, first, count);
     if (rc) return rc;
@@ -878,6 +892,32 @@ int rafthip_merge_acks(rafthip_engine* e, uint64_t first, uint64_t count, const 
     HIP_TRY(hipGetLastError());
     if (staged) HIP_TRY(hipStreamSynchronize(e->stream));
     e->stats.acks_applied += count * e->S;
+    return RAFTHIP_OK;
+}
+
+int rafthip_record_votes(rafthip_engine* e, const rafthip_msg* msgs, uint64_t n) {
+    if (!e) return fail(RAFTHIP_EINVAL, "engine is NULL");
+    if (n == 0) return RAFTHIP_OK;
+    if (!msgs) return fail(RAFTHIP_EINVAL, "msgs is NULL");
+    if (n > (1ull << 31)) return fail(RAFTHIP_EINVAL, "more than 2^31 vote records in one batch: split it");
+    DeviceGuard guard(e->device);
+    int rc;
+    if ((rc = ensure(e, e->votes, (size_t)e->S * e->stride))) return rc;
+    if ((rc = ensure(e, e->vote_first, (size_t)e->S * e->stride * sizeof(u32)))) return rc;
+    const void* d_recs = nullptr;
+    bool staged = false;
+    if ((rc = stage_records(e, msgs, n, &d_recs, &staged))) return rc;
+    const u32 blocks = (u32)((n + kBlock - 1) / kBlock);
+    const Msg* m = static_cast<const Msg*>(d_recs);
+    hipLaunchKernelGGL(k_record_votes<1>, dim3(blocks), dim3(kBlock), 0, e->stream, e->votes, e->vote_first, e->stride,
+                       e->G, e->S, m, (u32)n, e->d_rejected + 1);
+    hipLaunchKernelGGL(k_record_votes<2>, dim3(blocks), dim3(kBlock), 0, e->stream, e->votes, e->vote_first, e->stride,
+                       e->G, e->S, m, (u32)n, e->d_rejected + 1);
+    hipLaunchKernelGGL(k_record_votes<3>, dim3(blocks), dim3(kBlock), 0, e->stream, e->votes, e->vote_first, e->stride,
+                       e->G, e->S, m, (u32)n, e->d_rejected + 1);
+    HIP_TRY(hipGetLastError());
+    if (staged) HIP_TRY(hipStreamSynchronize(e->stream));
+    e->stats.msgs_ingested += n;
     return RAFTHIP_OK;
 }
 

@@ -254,11 +254,12 @@ def test_scenario_fixtures_on_the_gpu():
         with raft_amd.Engine(1, len(ids)) as e:
             e.set_uniform_config(len(ids))
             cells = np.zeros((len(ids), 1), dtype=np.uint8)
+            e.upload_votes(cells)
             for st in seq["steps"]:
-                for i, v in st["record"]:
-                    if cells[ids.index(i), 0] == 0:
-                        cells[ids.index(i), 0] = 2 if v else 1
-                e.upload_votes(cells)
+                recs = np.zeros(len(st["record"]), dtype=raft_amd.MSG_DTYPE)  # RecordVote on the device
+                for k, (i, v) in enumerate(st["record"]):
+                    recs[k] = (0, ids.index(i), raft_amd.capi.MSG_VOTE_RESP, 0 if v else 1, 0, 0)
+                e.record_votes(recs)
                 e.tally_votes()
                 res, gr, rj = e.read_vote_result()
                 assert (int(res[0]), int(gr[0]), int(rj[0])) == (names[st["result"]], st["granted"], st["rejected"]), (seq["src"], st)
@@ -307,3 +308,39 @@ def test_heartbeat_commit_cases_on_the_gpu():
             got = e.heartbeat_commit()
             for peer, want in c["want"].items():
                 assert int(got[c["ids"].index(int(peer)), 0]) == want, c["src"]
+
+
+@pytest.mark.parametrize("S", [3, 8, 9, 33, 64])
+def test_record_votes_first_vote_sticks(oracle, S):
+    """rafthip_record_votes vs RecordVote stepped one response at a time: conflicting duplicates inside
+    a batch, votes recorded before the batch, foreign records; then the tally."""
+    rng = np.random.default_rng(1900 + S)
+    G = 3001
+    votes = (rng.integers(0, 3, size=(S, G)) * (rng.random((S, G)) < 0.2)).astype(np.uint8)
+    m0, m1 = rand_masks(rng, S, G)
+    with raft_amd.Engine(G, S) as e:
+        e.upload_config(m0, m1)
+        e.upload_votes(votes)
+        want = votes.copy()
+        for rnd in range(3):
+            N = 40000
+            msgs = np.zeros(N, dtype=raft_amd.MSG_DTYPE)
+            msgs["group"] = rng.integers(0, G // (1 + 20 * rnd) + 3, size=N)  # later rounds pile onto few groups
+            msgs["slot"] = rng.integers(0, min(S + 1, 255), size=N)
+            msgs["type"] = rng.choice(np.array([6, 18, 4, 9], dtype=np.uint8), size=N, p=[0.5, 0.3, 0.1, 0.1])
+            msgs["reject"] = rng.integers(0, 2, size=N)
+            e.record_votes(msgs)
+            dropped = oracle.record_votes(want, msgs)
+            assert dropped > 0
+        e.tally_votes()
+        res, gr, rj = e.read_vote_result()
+        ores, ogr, orj = oracle.batch_tally_votes(want, in_mask=m0, out_mask=m1)
+        assert np.array_equal(res, ores) and np.array_equal(gr, ogr) and np.array_equal(rj, orj)
+        got = e.read_votes()
+        assert np.array_equal(got, want)
+        e.reset_votes()
+        e.record_votes(msgs[:10])  # after a reset every cell is open again
+        w2 = np.zeros((S, G), dtype=np.uint8)
+        oracle.record_votes(w2, msgs[:10])
+        e.tally_votes()
+        assert np.array_equal(e.read_vote_result()[0], oracle.batch_tally_votes(w2, in_mask=m0, out_mask=m1)[0])

@@ -146,3 +146,37 @@ def test_heartbeat_commit_cases(oracle):
         got = oracle.batch_heartbeat_commit(match, np.array([c["committed"]], dtype=np.uint64))
         for peer, want in c["want"].items():
             assert int(got[c["ids"].index(int(peer)), 0]) == want, c["src"]
+
+
+def _vote_records(pairs, ids, group=0):
+    msgs = np.zeros(len(pairs), dtype=oracle_msg_dtype())
+    for k, (i, v) in enumerate(pairs):
+        msgs[k] = (group, ids.index(i), 6, 0 if v else 1, 0, 0)
+    return msgs
+
+
+def oracle_msg_dtype():
+    from oracle import pyoracle
+    return pyoracle.MSG_DTYPE
+
+
+def test_record_votes_on_the_scenarios_and_first_vote_sticks(oracle):
+    """oracle.record_votes = RecordVote one response at a time (tracker/tracker.go:260-265): the vote
+    sequences of the reference's tests, then conflicting duplicates and foreign records."""
+    sc = _scenarios()
+    for seq in sc["vote_sequences"]:
+        ids = seq["voters"]
+        cells = np.zeros((len(ids), 1), dtype=np.uint8)
+        for st in seq["steps"]:
+            assert oracle.record_votes(cells, _vote_records(st["record"], ids)) == 0
+            res, gr, rj = oracle.batch_tally_votes(cells, uniform_voters=len(ids))
+            assert (int(res[0]), int(gr[0]), int(rj[0])) == (NAMES[st["result"]], st["granted"], st["rejected"]), (seq["src"], st)
+    cells = np.zeros((3, 2), dtype=np.uint8)
+    cells[2, 1] = 1  # recorded before the batch: sticks
+    msgs = np.zeros(7, dtype=oracle_msg_dtype())
+    msgs["group"] = [1, 1, 1, 1, 0, 5, 1]
+    msgs["slot"] = [0, 0, 2, 1, 3, 0, 1]
+    msgs["type"] = [6, 18, 6, 4, 6, 6, 18]
+    msgs["reject"] = [1, 0, 0, 0, 0, 0, 0]
+    assert oracle.record_votes(cells, msgs) == 3  # an MsgAppResp, a slot without a row, a group out of range
+    assert cells[:, 1].tolist() == [1, 2, 1] and not cells[:, 0].any()
