@@ -61,7 +61,7 @@ def test_random_call_sequences(oracle, S, G, seed):
         e.reset_votes()
         e.progress_config(cap, max_bytes)
         for step in range(150):
-            op = int(rng.integers(0, 20))
+            op = int(rng.integers(0, 21))
             checked[0] += 10 <= op < 16
             a, n = rng_range()
             if op == 0:
@@ -134,6 +134,16 @@ def test_random_call_sequences(oracle, S, G, seed):
                 fi = rng.integers(0, 30, size=n).astype(np.uint64)
                 e.upload_first_index(fi, first=a, count=n)
                 first_index[a:a + n] = fi
+            elif op == 20:
+                k = int(rng.integers(0, 500))
+                msgs = np.zeros(k, dtype=raft_amd.MSG_DTYPE)
+                msgs["group"] = rng.integers(0, G + 2, size=k)
+                msgs["slot"] = rng.integers(0, min(S + 1, 255), size=k)
+                msgs["type"] = rng.choice(np.array([6, 18, 4], dtype=np.uint8), size=k)
+                msgs["reject"] = rng.integers(0, 2, size=k)
+                e.record_votes(msgs)
+                oracle.record_votes(sh["votes"], msgs)
+                assert np.array_equal(e.read_votes(a, n), sh["votes"][:, a:a + n]), step
             elif op in (18, 19):
                 k = int(rng.integers(0, 600))
                 msgs, aux = pu.random_events(rng, k, S, G, pl, hot_cells=int(rng.integers(0, 4)))
