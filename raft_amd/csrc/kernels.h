@@ -118,6 +118,26 @@ __device__ __forceinline__ void sort_asc_batcher(u64 (&v)[N]) {
     batcher_impl<N>(v, std::make_integer_sequence<int, Batcher<N>::n>{});
 }
 
+// The same network on (key, tag) pairs: the tag rides along with its key.
+template <int A, int B, int N>
+__device__ __forceinline__ void cex_tagged(u64 (&v)[N], u32 (&w)[N]) {
+    const u64 x = v[A], y = v[B];
+    const u32 p = w[A], q = w[B];
+    const bool lt = x < y;
+    v[A] = lt ? x : y;
+    v[B] = lt ? y : x;
+    w[A] = lt ? p : q;
+    w[B] = lt ? q : p;
+}
+template <int N, int... K>
+__device__ __forceinline__ void batcher_tagged_impl(u64 (&v)[N], u32 (&w)[N], std::integer_sequence<int, K...>) {
+    (cex_tagged<Batcher<N>::list.ce[K].a, Batcher<N>::list.ce[K].b, N>(v, w), ...);
+}
+template <int N>
+__device__ __forceinline__ void sort_asc_batcher_tagged(u64 (&v)[N], u32 (&w)[N]) {
+    batcher_tagged_impl<N>(v, w, std::make_integer_sequence<int, Batcher<N>::n>{});
+}
+
 // Minimal networks up to 8 keys, Batcher's above.
 template <int N>
 __device__ __forceinline__ void sort_keys(u64 (&v)[N]) {
@@ -434,6 +454,40 @@ __device__ __forceinline__ u64 regs_half(const u64* __restrict__ match, u64 stri
 
 // 48 / 64 keys: ask for 3 waves per SIMD (<= 168 VGPRs); left alone the
 // compiler takes 186 and drops to 2 (measured 632 -> 576 us at 2^22 x 64).
+// Both halves of a joint config from ONE sort: every key carries two tag bits
+// (member of the incoming / of the outgoing half); after the sort a scan from the
+// largest key down counts members per half and picks each half's q-th largest.
+// A tagged compare-exchange costs 7 operations against 5, so this is 1.4 sorts'
+// worth of work instead of the 2 sorts (and second key load) of zeroing the
+// non-members per half.
+template <int N>
+__device__ __forceinline__ u64 regs_joint(const u64* __restrict__ match, u64 stride, int S, u64 m0, u64 m1) {
+    u64 a[N];
+    u32 tag[N];
+    const u64* base = match + (u64)blockIdx.x * kBlock;
+    const u32 t = threadIdx.x;
+#pragma unroll
+    for (int s = 0; s < N; ++s) {
+        const u64* p = base + (u64)(s < S ? s : 0) * stride;  // rows >= S: re-read row 0, tag 0 (masks have no bit there)
+        asm volatile("" : "+s"(p));
+        a[s] = __builtin_nontemporal_load(p + t);
+        tag[s] = (u32)((m0 >> s) & 1ull) | ((u32)((m1 >> s) & 1ull) << 1);
+    }
+    sort_asc_batcher_tagged<N>(a, tag);
+    const u32 q0 = (u32)__popcll(m0) / 2 + 1, q1 = (u32)__popcll(m1) / 2 + 1;
+    u32 c0 = 0, c1 = 0;
+    u64 r0 = kU64Max, r1 = kU64Max;  // an empty half is never hit: MaxUint64, the identity of min
+#pragma unroll
+    for (int i = N - 1; i >= 0; --i) {
+        const u32 in0 = tag[i] & 1u, in1 = tag[i] >> 1;
+        c0 += in0;
+        c1 += in1;
+        r0 = (in0 != 0 && c0 == q0) ? a[i] : r0;
+        r1 = (in1 != 0 && c1 == q1) ? a[i] : r1;
+    }
+    return r0 < r1 ? r0 : r1;
+}
+
 template <int N, typename MaskT, int MODE>
 __global__ __launch_bounds__(kBlock, (N > 32 ? 3 : 1)) void k_commit_regs(const u64* __restrict__ match, u64 stride, u64 G,
                                                         int S, const MaskT* __restrict__ in_mask,
@@ -457,14 +511,20 @@ __global__ __launch_bounds__(kBlock, (N > 32 ? 3 : 1)) void k_commit_regs(const 
     }
     u64 res;
     if (__any(m1 != 0)) {
-        // Joint wave: one rolled loop over the two halves, so the keys are loaded
-        // per half (the second read hits L2) instead of being kept twice in
-        // registers.  An empty half yields MaxUint64, the identity of min.
-        res = kU64Max;
+        if constexpr (N <= 32) {
+            // Joint wave: one tagged sort serves both halves (regs_joint).
+            res = regs_joint<N>(match, stride, S, m0, m1);
+        } else {
+            // Above 32 keys the tags do not fit the register budget of 3 waves per SIMD
+            // (they spill: 4.5 ms instead of 1 ms at 64 keys): one rolled loop over the
+            // two halves, keys re-loaded per half (the second read hits L2).  An empty
+            // half yields MaxUint64, the identity of min.
+            res = kU64Max;
 #pragma unroll 1
-        for (int h = 0; h < 2; ++h) {
-            const u64 r = regs_half<N, false>(match, stride, S, h ? m1 : m0);
-            res = r < res ? r : res;
+            for (int h = 0; h < 2; ++h) {
+                const u64 r = regs_half<N, false>(match, stride, S, h ? m1 : m0);
+                res = r < res ? r : res;
+            }
         }
     } else {
         res = regs_half<N, true>(match, stride, S, m0);
