@@ -191,6 +191,8 @@ def main():
     # on the engine stream and replayed — the per-launch host cost is gone, what remains is the
     # kernel plus the kernel-to-kernel boundary on the device
     try:
+        if world > 1:  # single-GPU measurement extra: no stream capture next to a live RCCL communicator
+            raise RuntimeError("skipped at n_gpus > 1")
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, stream=stream):
             for e in engines:
