@@ -43,7 +43,7 @@ SYMBOLS = [
     "rafthip_progress_config", "rafthip_upload_progress", "rafthip_read_progress", "rafthip_upload_inflights",
     "rafthip_read_inflights", "rafthip_upload_first_index", "rafthip_step_progress", "rafthip_step_wire",
     "rafthip_merge_acks", "rafthip_host_alloc", "rafthip_host_free",
-    "rafthip_record_votes", "rafthip_read_votes",
+    "rafthip_record_votes", "rafthip_read_votes", "rafthip_step_dense",
 ]
 MSG_VOTE_RESP, MSG_PRE_VOTE_RESP = 6, 18
 
@@ -169,6 +169,7 @@ def load_library():
         "rafthip_step_progress": (i32, [vp, vp, vp, u64, vp]),
         "rafthip_step_wire": (i32, [vp, vp, vp, vp, u64, vp, vp, vp, vp]),
         "rafthip_merge_acks": (i32, [vp, u64, u64, vp, u64]),
+        "rafthip_step_dense": (i32, [vp, u64, u64, vp, u64, vp, vp, vp, u64]),
         "rafthip_record_votes": (i32, [vp, vp, u64]),
         "rafthip_read_votes": (i32, [vp, u64, u64, vp, u64]),
         "rafthip_host_alloc": (i32, [C.POINTER(vp), u64]),
@@ -448,6 +449,14 @@ class Engine:
             n = len(msgs)
         actions = np.zeros(n, dtype=np.uint8) if want_actions else None
         _check(self._L.rafthip_step_progress(self._h, _ptr(msgs), _ptr(aux), n, _ptr(actions)))
+        return actions
+
+    def step_dense(self, acks=None, hb_mask=None, hb_ctx_mask=None, first=0, count=None, want_actions=True):
+        """Dense tick: acks u64 [S][count] (index + 1, 0 = none), heartbeat-response slot masks [count]."""
+        first, count = self._range(first, count)
+        actions = np.zeros((self.S, count), dtype=np.uint8) if want_actions else None
+        _check(self._L.rafthip_step_dense(self._h, first, count, _ptr(acks), count, _ptr(hb_mask), _ptr(hb_ctx_mask),
+                                          _ptr(actions), count))
         return actions
 
     def step_wire(self, data, offsets, groups, n=None):

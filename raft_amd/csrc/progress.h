@@ -341,6 +341,82 @@ __global__ __launch_bounds__(kBlock) void k_progress_apply(const Msg* __restrict
     if (p.read_ack) or_slot_bit(acks, mbytes, own.group, own.slot);
 }
 
+// K9d — the same stepping when a tick's responses are dense: an ack plane
+// (acks[slot][group] = acknowledged index + 1, 0 = no MsgAppResp from that peer)
+// and a heartbeat-response bitmask per group.  One event of each kind per
+// Progress at most, so there is nothing to order between lanes: lane = group,
+// loop over slots, every access a coalesced stream (32-byte records, Match, ack
+// and ring planes).  Per Progress: the MsgAppResp first, then the
+// MsgHeartbeatResp.  A wave writes a slot's records back only if one of its
+// lanes stepped (whole-line stores).  out[slot][group] = the two action bytes
+// or-ed (they share no bit: an accepted ack never asks for sendAppend, a
+// heartbeat response asks for nothing else).
+template <typename MaskT>
+__global__ __launch_bounds__(kBlock) void k_progress_dense(ProgPlanes pl, u64 first, u64 count, u32 S,
+                                                           const u64* __restrict__ acks_plane, u64 ack_stride,
+                                                           const MaskT* __restrict__ hb, const MaskT* __restrict__ hb_ctx,
+                                                           MaskT* __restrict__ active, MaskT* __restrict__ rd_acks,
+                                                           const u64* __restrict__ term_last,
+                                                           const u64* __restrict__ first_index,
+                                                           uint8_t* __restrict__ out, u64 out_stride) {
+    const u64 i = (u64)blockIdx.x * kBlock + threadIdx.x;
+    const bool live = i < count;
+    const u64 g = first + (live ? i : 0);
+    const u64 hbm = live && hb ? (u64)hb[i] : 0, ctxm = live && hb_ctx ? (u64)hb_ctx[i] : 0;
+    u64 act_bits = 0, ack_bits = 0;
+    for (u32 s = 0; s < S; ++s) {
+        const u64 cell = (u64)s * pl.stride + g;
+        const u64 av = live && acks_plane ? acks_plane[(u64)s * ack_stride + i] : 0;
+        const bool has_ack = av != 0, has_hb = ((hbm >> s) & 1ull) != 0;
+        const bool any = has_ack || has_hb;
+        if (!__any(any)) {
+            if (live && out) out[(u64)s * out_stride + i] = 0;
+            continue;
+        }
+        u64* rw = reinterpret_cast<u64*>(pl.rec + cell);
+        Vec<u64, 2> r0, r1;
+        if (live) {
+            r0 = load_vec<u64, 2>(rw);
+            r1 = load_vec<u64, 2>(rw + 2);
+        }
+        uint8_t act = 0;
+        if (any) {
+            Prog p;
+            const u64 match0 = pl.match[cell];
+            const u32 meta = (u32)r1.v[1];
+            p.match = match0;
+            p.next = r0.v[0];
+            p.pending = r0.v[1];
+            p.ibytes = r1.v[0];
+            p.state = (meta >> 29) & 3u;
+            p.paused = meta >> 31;
+            p.istart = meta & 0x3FFFu;
+            p.icount = (meta >> 14) & 0x7FFFu;
+            p.active = p.read_ack = false;
+            const u64* fi = first_index ? first_index + g : nullptr;
+            if (has_ack) act |= prog_step(p, pl, cell, kMsgAppResp, false, 0, av - 1, 0, term_last + g, fi);
+            if (has_hb)
+                act |= prog_step(p, pl, cell, kMsgHeartbeatResp, false, (u32)((ctxm >> s) & 1ull), 0, 0, term_last + g, fi);
+            if (p.match != match0) pl.match[cell] = p.match;
+            r0.v[0] = p.next;
+            r0.v[1] = p.pending;
+            r1.v[0] = p.ibytes;
+            r1.v[1] = (u64)rec_meta(p.istart, p.icount, p.state | (p.paused << 2)) | (r1.v[1] & 0xFFFFFFFF00000000ull);
+            act_bits |= (u64)p.active << s;
+            ack_bits |= (u64)p.read_ack << s;
+        }
+        if (live) {
+            store_vec<u64, 2>(rw, r0);
+            store_vec<u64, 2>(rw + 2, r1);
+            if (out) out[(u64)s * out_stride + i] = act;
+        }
+    }
+    if (live) {
+        if (act_bits) active[g] = (MaskT)(active[g] | (MaskT)act_bits);
+        if (ack_bits) rd_acks[g] = (MaskT)(rd_acks[g] | (MaskT)ack_bits);
+    }
+}
+
 // ---- SoA <-> record conversion for the upload / read entry points -----------
 // (the C ABI speaks [slot][group] planes like every other call)
 

@@ -1380,6 +1380,76 @@ static int progress_passes(rafthip_engine* e, const Msg* d_msgs, const u64* d_au
     return RAFTHIP_OK;
 }
 
+int rafthip_step_dense(rafthip_engine* e, uint64_t first, uint64_t count, const uint64_t* acks, uint64_t ack_stride,
+                       const void* hb_mask, const void* hb_ctx_mask, uint8_t* actions, uint64_t act_stride) {
+    int rc = need_progress(e);
+    if (rc || (rc = check_range(e, first, count))) return rc;
+    if (acks && ack_stride < count)
+        return fail(RAFTHIP_EINVAL, "ack_stride %llu < count %llu", (u64)ack_stride, (u64)count);
+    if (actions && act_stride < count)
+        return fail(RAFTHIP_EINVAL, "act_stride %llu < count %llu", (u64)act_stride, (u64)count);
+    if (hb_ctx_mask && !hb_mask) return fail(RAFTHIP_EINVAL, "hb_ctx_mask without hb_mask");
+    if (count == 0 || (!acks && !hb_mask)) return RAFTHIP_OK;
+    DeviceGuard guard(e->device);
+    const size_t mb = (size_t)e->mbytes, plane_b = (size_t)e->stride * mb;
+    if ((rc = ensure(e, e->active, plane_b))) return rc;
+    if ((rc = ensure(e, e->acks, plane_b))) return rc;
+    // host inputs are staged; device (or page-locked) ones are read in place
+    const void *d_acks = nullptr, *d_hb = nullptr, *d_ctx = nullptr;
+    u64 d_ack_stride = ack_stride;
+    if (acks) {
+        if (is_device_ptr(acks)) {
+            d_acks = acks;
+        } else {
+            d_ack_stride = count;
+            if ((rc = stage_reserve(e, 5, (size_t)count * e->S * sizeof(u64)))) return rc;
+            if ((rc = copy_rows(e, e->stage_buf[5], count * 8, acks, ack_stride * 8, count * 8, e->S))) return rc;
+            d_acks = e->stage_buf[5];
+            e->stats.bytes_uploaded += count * 8 * e->S;
+        }
+    }
+    if (hb_mask && (rc = stage_input(e, 1, hb_mask, (size_t)count * mb, &d_hb))) return rc;
+    if (hb_ctx_mask && (rc = stage_input(e, 2, hb_ctx_mask, (size_t)count * mb, &d_ctx))) return rc;
+    const bool act_host = actions && !is_device_ptr(actions);
+    uint8_t* d_act = actions;
+    u64 d_act_stride = act_stride;
+    if (act_host) {
+        d_act_stride = count;
+        if ((rc = stage_reserve(e, 6, (size_t)count * e->S))) return rc;
+        d_act = static_cast<uint8_t*>(e->stage_buf[6]);
+    }
+    e->pp.match = e->match;
+    const u32 blocks = (u32)((count + kBlock - 1) / kBlock);
+#define RAFTHIP_DENSE(MT)                                                                                          \
+    hipLaunchKernelGGL((k_progress_dense<MT>), dim3(blocks), dim3(kBlock), 0, e->stream, e->pp, (u64)first,         \
+                       (u64)count, e->S, static_cast<const u64*>(d_acks), d_ack_stride,                              \
+                       static_cast<const MT*>(d_hb), static_cast<const MT*>(d_ctx), static_cast<MT*>(e->active),     \
+                       static_cast<MT*>(e->acks), static_cast<const u64*>(e->term_last),                             \
+                       static_cast<const u64*>(e->first_index), d_act, d_act_stride)
+    if (e->mbytes == 1) {
+        RAFTHIP_DENSE(uint8_t);
+    } else if (e->mbytes == 2) {
+        RAFTHIP_DENSE(uint16_t);
+    } else if (e->mbytes == 4) {
+        RAFTHIP_DENSE(uint32_t);
+    } else {
+        RAFTHIP_DENSE(uint64_t);
+    }
+#undef RAFTHIP_DENSE
+    HIP_TRY(hipGetLastError());
+    bool wait = d_acks != acks || (hb_mask && d_hb != hb_mask) || (hb_ctx_mask && d_ctx != hb_ctx_mask) ||
+                e->zero_copy_pending;
+    e->zero_copy_pending = false;
+    if (act_host) {
+        if ((rc = copy_rows(e, actions, act_stride, d_act, count, count, e->S))) return rc;
+        e->stats.bytes_downloaded += count * e->S;
+        wait = true;
+    }
+    if (wait) HIP_TRY(hipStreamSynchronize(e->stream));
+    e->stats.msgs_ingested += count * e->S;
+    return RAFTHIP_OK;
+}
+
 int rafthip_step_progress(rafthip_engine* e, const rafthip_msg* msgs, const uint64_t* aux, uint64_t n,
                           uint8_t* actions) {
     int rc = need_progress(e);

@@ -187,3 +187,59 @@ def test_leader_tick_with_progress_full_size():
         assert_state(e, pl, active, acks, last)
         assert np.array_equal(e.read_commit(), po.batch_committed(pl["match"], uniform_voters=V, threads=0))
         assert (want == capi.ACT_DEFERRED).sum() == 0 and (want & capi.ACT_UPDATED).any()
+
+
+def dense_as_events(acks, hb, ctx, S, G, first=0):
+    """The event stream rafthip_step_dense stands for: every MsgAppResp, then every MsgHeartbeatResp."""
+    ss, gg = np.nonzero(acks)
+    a = np.zeros(len(ss), dtype=raft_amd.MSG_DTYPE)
+    a["slot"], a["group"], a["type"], a["index"] = ss, gg + first, capi.MSG_APP_RESP, acks[ss, gg] - np.uint64(1)
+    bits = (hb.astype(np.uint64)[None, :] >> np.arange(S, dtype=np.uint64)[:, None]) & np.uint64(1)
+    cbits = (ctx.astype(np.uint64)[None, :] >> np.arange(S, dtype=np.uint64)[:, None]) & np.uint64(1)
+    hs, hg = np.nonzero(bits)
+    h = np.zeros(len(hs), dtype=raft_amd.MSG_DTYPE)
+    h["slot"], h["group"], h["type"], h["flags"] = hs, hg + first, capi.MSG_HEARTBEAT_RESP, cbits[hs, hg]
+    return np.concatenate([a, h]), (ss, gg), (hs, hg)
+
+
+@pytest.mark.parametrize("S,cap,mb,first_off", [(3, 4, 0, 0), (7, 2, 90, 5), (9, 4, 0, 0), (16, 3, 0, 17), (40, 2, 0, 0), (64, 1, 0, 3)])
+def test_dense_step_equals_the_event_stream(S, cap, mb, first_off):
+    """rafthip_step_dense (ack plane + heartbeat-response masks) = the same responses as records through
+    the oracle: every MsgAppResp, then every MsgHeartbeatResp; states, Inflights, bit planes, actions."""
+    rng = np.random.default_rng(2100 + S)
+    G = 2501
+    pl = pu.random_planes(rng, S, G, cap, mb)
+    mdt = pu.gu.mask_dtype(S)
+    last = pl["match"].max(axis=0) + rng.integers(0, 3, size=G).astype(np.uint64)
+    firsti = rng.integers(0, 1 << 19, size=G).astype(np.uint64)
+    active, acks_bits = pu.mask_planes(S, G)
+    active[:] = rng.integers(0, 4, size=G)
+    cnt = G - first_off - 2
+    full = np.uint64((1 << S) - 1) if S < 64 else np.uint64(pu.gu.U64MAX)
+    with raft_amd.Engine(G, S) as e:
+        upload_state(e, pl, cap, mb, active, acks_bits, last, firsti)
+        for rnd in range(3):
+            near = np.where(rng.random((S, cnt)) < 0.5, pl["match"][:, first_off:first_off + cnt],
+                            pl["next"][:, first_off:first_off + cnt]) + rng.integers(0, 6, size=(S, cnt)).astype(np.uint64)
+            plane = np.where(rng.random((S, cnt)) < (0.6 if rnd else 0.05), near + np.uint64(1), 0).astype(np.uint64)
+            hb = (rng.integers(0, 1 << 63, size=cnt, dtype=np.uint64) * np.uint64(2) + np.uint64(rnd & 1)) & full
+            hb = np.where(rng.random(cnt) < 0.7, hb, 0).astype(mdt)
+            ctx = (hb & rng.integers(0, 1 << 63, size=cnt, dtype=np.uint64).astype(mdt)).astype(mdt)
+            plane = np.ascontiguousarray(plane)
+            act = e.step_dense(plane, np.ascontiguousarray(hb), np.ascontiguousarray(ctx), first=first_off, count=cnt)
+            ev, (ss, gg), (hs, hg) = dense_as_events(plane, hb, ctx, S, cnt, first_off)
+            want = po.step_progress(pl, cap, mb, active, acks_bits, last, firsti, ev, None, limit=1 << 30)
+            wact = np.zeros((S, cnt), dtype=np.uint8)
+            wact[ss, gg] |= want[:len(ss)]
+            wact[hs, hg] |= want[len(ss):]
+            assert np.array_equal(act, wact), rnd
+            assert_state(e, pl, active, acks_bits, last)
+        assert (wact & capi.ACT_UPDATED).any() and (wact & capi.ACT_SEND_APPEND).any()
+        # device-resident inputs, no actions wanted, acks only
+        import torch
+        d = torch.from_numpy(plane.view(np.int64)).cuda()
+        L = raft_amd.load_library()
+        assert L.rafthip_step_dense(e._h, first_off, cnt, d.data_ptr(), cnt, None, None, None, 0) == 0
+        ev, _, _ = dense_as_events(plane, np.zeros(cnt, dtype=mdt), np.zeros(cnt, dtype=mdt), S, cnt, first_off)
+        po.step_progress(pl, cap, mb, active, acks_bits, last, firsti, ev, None, limit=1 << 30)
+        assert_state(e, pl, active, acks_bits, last)

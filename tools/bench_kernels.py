@@ -245,6 +245,33 @@ def main():
             timed("k_progress_link + k_progress_apply, random cells (K9)", "event", N, 106,
                   lambda: L.rafthip_step_progress(e._h, d_ev.data_ptr(), d_aux.data_ptr(), N, d_act.data_ptr()))
         del pl, ev, aux, d_ev, d_aux, d_act
+    # dense tick through the Progress stepper (K9d): the same 4*G acks as a plane + heartbeat masks
+    if not args.only or args.only in "k_progress_dense (K9d)":
+        import progress_util as pu
+        cap = 4
+        pl = pu.random_planes(rng, Sv, G, cap, 0)
+        pl["pstate"][:] = 1
+        plane = np.zeros((Sv, G), dtype=np.uint64)
+        np.maximum.at(plane, (recs["slot"], recs["group"]), pl["match"][recs["slot"], recs["group"]] + np.uint64(3))
+        d_plane = torch.from_numpy(plane.view(np.int64)).to(dev)
+        hbm = rng.integers(0, 1 << Sv, size=G).astype(np.uint16)
+        d_hb = torch.from_numpy(hbm.view(np.int16)).to(dev)
+        d_act = torch.zeros((Sv, G), dtype=torch.uint8, device=dev)
+        L = raft_amd.load_library()
+        with raft_amd.Engine(G, Sv, stream=stream.cuda_stream) as e:
+            e.set_uniform_config(7)
+            e.progress_config(cap, 0)
+            e.upload_match(pl["match"])
+            e.upload_progress(pl["pstate"], pl["next"], pl["pending"])
+            e.upload_inflights(pl["infl_meta"], pl["infl_bytes"], pl["ring_index"], pl["ring_bytes"])
+            e.upload_term_range(np.zeros(G, dtype=np.uint64), pl["match"].max(axis=0) + np.uint64(16))
+            nev = int(np.count_nonzero(plane)) + int(sum(bin(int(x)).count("1") for x in hbm[:4096])) * (G // 4096)
+            # per cell: ack 8 + Match 8 + record 32 read and written + action 1; per group: masks and last index
+            timed("k_progress_dense, %.0f %% acked + %.0f %% heartbeat responses (K9d)" % (
+                100.0 * np.count_nonzero(plane) / plane.size, 50.0), "cell", Sv * G, 81,
+                lambda: L.rafthip_step_dense(e._h, 0, G, d_plane.data_ptr(), G, d_hb.data_ptr(), None, d_act.data_ptr(), G))
+            print(json.dumps({"K9d_events_per_launch": nev}), flush=True)
+        del pl, plane, d_plane, d_hb, d_act
     # the same 4*G acks as a dense [slot][group] plane (K5d)
     if not args.only or args.only in "k_merge_acks, dense plane (K5d)":
         plane = np.zeros((Sv, G), dtype=np.uint64)
