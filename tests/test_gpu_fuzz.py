@@ -61,7 +61,7 @@ def test_random_call_sequences(oracle, S, G, seed):
         e.reset_votes()
         e.progress_config(cap, max_bytes)
         for step in range(150):
-            op = int(rng.integers(0, 21))
+            op = int(rng.integers(0, 22))
             checked[0] += 10 <= op < 16
             a, n = rng_range()
             if op == 0:
@@ -134,6 +134,26 @@ def test_random_call_sequences(oracle, S, G, seed):
                 fi = rng.integers(0, 30, size=n).astype(np.uint64)
                 e.upload_first_index(fi, first=a, count=n)
                 first_index[a:a + n] = fi
+            elif op == 21:
+                from test_gpu_progress import dense_as_events
+                near = sh["match"][:, a:a + n] + rng.integers(0, 8, size=(S, n)).astype(np.uint64)
+                plane = np.ascontiguousarray(np.where(rng.random((S, n)) < 0.5, near + np.uint64(1), 0).astype(np.uint64))
+                hb, _ = rand_masks(rng, S, max(n, 1), joint_frac=0, empty_frac=0.3)
+                hb = np.ascontiguousarray(hb[:n])
+                ctx = np.ascontiguousarray(hb & rand_masks(rng, S, max(n, 1), joint_frac=0, empty_frac=0.3)[0][:n])
+                act = e.step_dense(plane, hb, ctx, first=a, count=n)
+                ev, (ss, gg), (hs, hg) = dense_as_events(plane, hb, ctx, S, n, a)
+                want = po.step_progress(pl, cap, max_bytes, sh["active"], sh["acks"], sh["tl"], first_index, ev, None,
+                                        limit=1 << 30)
+                wact = np.zeros((S, n), dtype=np.uint8)
+                wact[ss, gg] |= want[:len(ss)]
+                wact[hs, hg] |= want[len(ss):]
+                assert np.array_equal(act, wact), step
+                got = e.read_progress()
+                for key in PKEYS:
+                    assert np.array_equal(got[key], pl[key]), (step, key)
+                assert np.array_equal(e.read_match(), sh["match"]), step
+                assert np.array_equal(e.read_active(), sh["active"]), step
             elif op == 20:
                 k = int(rng.integers(0, 500))
                 msgs = np.zeros(k, dtype=raft_amd.MSG_DTYPE)
