@@ -89,12 +89,38 @@ def main():
                         times[name].append(e0.elapsed_time(e1))
                     if name == "commit_advance":
                         advanced = r[1]
+        # the same tick when the transport hands the responses over densely: an ack plane + heartbeat masks
+        plane = np.zeros((S, G), dtype=np.uint64)
+        np.maximum.at(plane, (slots, groups), pl["match"][slots, groups] + rng.integers(2, 64, size=N).astype(np.uint64))
+        d_plane = torch.from_numpy(plane.view(np.int64)).to(dev)
+        hbm = rng.integers(0, 1 << S, size=G).astype(np.uint16)
+        d_hb = torch.from_numpy(hbm.view(np.int16)).to(dev)
+        d_dact = torch.zeros((S, G), dtype=torch.uint8, device=dev)
+        dense_events = int(np.count_nonzero(plane)) + int(np.unpackbits(hbm.view(np.uint8)).sum())
+        stages_d = [("step_dense", lambda: L.rafthip_step_dense(e._h, 0, G, d_plane.data_ptr(), G, d_hb.data_ptr(), None,
+                                                                d_dact.data_ptr(), G))] + stages[1:]
+        times_d = {k: [] for k, _ in stages_d}
+        with torch.cuda.stream(stream):
+            for it in range(4):
+                reset()
+                torch.cuda.synchronize()
+                for name, fn in stages_d:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(stream)
+                    fn()
+                    e1.record(stream)
+                    e1.synchronize()
+                    if it:
+                        times_d[name].append(e0.elapsed_time(e1))
+        out_d = {k: round(float(np.median(v)), 3) for k, v in times_d.items()}
         out = {k: round(float(np.median(v)), 3) for k, v in times.items()}
         tick = sum(out.values())
         print(json.dumps({"groups": G, "slots": S, "messages": N, "bytes_per_message": round(len(data) / N, 1),
                           "stage_ms": out, "tick_ms": round(tick, 3), "messages_per_s": N / tick * 1e3,
                           "groups_advanced": int(advanced), "applied": int((d_status == 0).sum().item()),
-                          "updated": int(((d_act & 2) != 0).sum().item())}))
+                          "updated": int(((d_act & 2) != 0).sum().item()),
+                          "dense": {"events": dense_events, "stage_ms": out_d, "tick_ms": round(sum(out_d.values()), 3),
+                                    "events_per_s": dense_events / sum(out_d.values()) * 1e3}}))
 
 
 if __name__ == "__main__":
