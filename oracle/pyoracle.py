@@ -281,6 +281,16 @@ def raftlog_maybe_commit(first_index, snap_term, terms, committed, max_index, te
     return bool(ok), c.value
 
 
+def find_conflict_by_term(first_index, snap_term, terms, index, term):
+    """raftLog.findConflictByTerm(index, term) on an explicit log -> (guess index, its term or 0)."""
+    t = np.ascontiguousarray(np.asarray(terms, dtype=np.uint64))
+    out = C.c_uint64(0)
+    f = lib().oracle_find_conflict_by_term
+    f.restype = C.c_uint64
+    f.argtypes = [C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p]
+    return int(f(first_index, snap_term, _vp(t), len(t), index, term, C.byref(out))), out.value
+
+
 def committed_entry_in_current_term(first_index, snap_term, terms, committed, term):
     """raft.committedEntryInCurrentTerm on an explicit log."""
     t = np.ascontiguousarray(np.asarray(terms, dtype=np.uint64))

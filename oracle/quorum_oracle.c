@@ -614,6 +614,30 @@ ORACLE_API int oracle_raftlog_maybe_commit(uint64_t first_index, uint64_t snap_t
     return raftlog_maybe_commit(&l, committed, max_index, term);
 }
 
+/* log.go:178-190 — raftLog.findConflictByTerm: the largest guess <= index whose term is <= term,
+ * or whose term is unknown (compacted / not yet stored: log.go:381-407 returns an error there, which
+ * is not the same as a term of 0).  *term_out = term(guess), 0 when unknown.  The leader runs it on
+ * the RejectHint / LogTerm of a rejected MsgAppResp (raft.go:1460-1461) before MaybeDecrTo. */
+ORACLE_API uint64_t oracle_find_conflict_by_term(uint64_t first_index, uint64_t snap_term,
+                                                 const uint64_t *terms, uint64_t n, uint64_t index,
+                                                 uint64_t term, uint64_t *term_out) {
+    oracle_log l = {first_index, snap_term, terms, n};
+    uint64_t last = l.first_index + l.n - 1;
+    for (; index > 0; index--) {
+        if (index + 1 < l.first_index || index > last) { /* ErrCompacted / ErrUnavailable */
+            if (term_out) *term_out = 0;
+            return index;
+        }
+        uint64_t ours = log_term_or_zero(&l, index);
+        if (ours <= term) {
+            if (term_out) *term_out = ours;
+            return index;
+        }
+    }
+    if (term_out) *term_out = 0;
+    return 0;
+}
+
 /*
  * raft.go:755-758 — raft.maybeCommit over G groups: mci = trk.Committed(), then
  * raftLog.maybeCommit(mci, r.Term).  Group g's log is entries
