@@ -278,10 +278,27 @@ int rafthip_upload_term(rafthip_engine *e, uint64_t first, uint64_t count, const
  * held little-endian in ctx[g] (byte i of the context = bits 8i..8i+7). */
 int rafthip_upload_read_ctx(rafthip_engine *e, uint64_t first, uint64_t count, const uint64_t *ctx,
                             const uint8_t *ctx_len);
+/* The vote response type each group's campaign counts — stepCandidate's
+ * myVoteRespType, raft.go:1628-1633: RAFTHIP_MSG_PRE_VOTE_RESP for a
+ * StatePreCandidate, RAFTHIP_MSG_VOTE_RESP for a StateCandidate, 0 for every
+ * other state (leaders and followers ignore vote responses).  While any group
+ * has one, the wire entry points also step vote responses: after the term gate
+ * of raft.Step — a granted MsgPreVoteResp passes with a higher term, it carries
+ * the pre-candidate's future term (raft.go:1068-1076) — a response of the
+ * group's own type from a peer with a Progress row is recorded as
+ * rafthip_record_votes records it (raft.poll, raft.go:1041-1049) and comes back
+ * RAFTHIP_WIRE_VOTE; the other type, or a group that is not campaigning:
+ * RAFTHIP_WIRE_OTHER_TYPE.  Follow with rafthip_tally_votes: the result after a
+ * batch is the result the reference reaches one response at a time (Won and
+ * Lost are final: a later vote moves one peer from `missing` to yes or no and
+ * can undo neither); rafthip_reset_votes when a campaign starts
+ * (ProgressTracker.ResetVotes, raft.go:784).  resp_type NULL with the whole
+ * range clears every group and turns the vote passes off again. */
+int rafthip_upload_campaign(rafthip_engine *e, uint64_t first, uint64_t count, const uint8_t *resp_type);
 
 /* What happened to one serialized message (rafthip_ingest_wire). */
 #define RAFTHIP_WIRE_APPLIED 0     /* stepped as rafthip_ingest_msgs steps its record */
-#define RAFTHIP_WIRE_OTHER_TYPE 1  /* well-formed, not MsgAppResp / MsgHeartbeatResp: the host steps it */
+#define RAFTHIP_WIRE_OTHER_TYPE 1  /* well-formed, not a response this path steps: the host steps it */
 #define RAFTHIP_WIRE_NO_PROGRESS 2 /* no Progress for m.From: dropped, raft.go:1327-1331 */
 #define RAFTHIP_WIRE_STALE_TERM 3  /* m.Term < r.Term: ignored, raft.go:1087-1138 */
 #define RAFTHIP_WIRE_HIGHER_TERM 4 /* m.Term > r.Term: the host must step down (raft.go:1056-1085); not applied */
@@ -291,7 +308,8 @@ int rafthip_upload_read_ctx(rafthip_engine *e, uint64_t first, uint64_t count, c
 #define RAFTHIP_WIRE_BAD_GROUP 7   /* envelope group id >= num_groups */
 #define RAFTHIP_WIRE_NEEDS_LOG 8   /* rafthip_step_wire only: a rejection with LogTerm > 0, whose next probe index needs
                                       findConflictByTerm on the leader's log (raft.go:1458): the host steps it */
-#define RAFTHIP_WIRE_STATUSES 9
+#define RAFTHIP_WIRE_VOTE 9        /* a vote response of the group's campaign (rafthip_upload_campaign): recorded */
+#define RAFTHIP_WIRE_STATUSES 10
 #define RAFTHIP_MSG_NEEDS_HOST 0xFE /* record type of such a message: it and every later event of the same Progress
                                        in the batch come back RAFTHIP_ACT_DEFERRED, so stream order per Progress holds */
 #define RAFTHIP_MSGF_HAS_CTX 2     /* out record flag: Message.Context is non-empty */

@@ -111,6 +111,27 @@ func (b *BatchEngine) StepWire(bytes []byte, offsets []uint64, groups []uint32, 
 		(*C.uint8_t)(unsafe.Pointer(&actions[0]))))
 }
 
+// Campaign: group starts (respType = MsgPreVoteResp or MsgVoteResp, stepCandidate's myVoteRespType,
+// raft.go:1628-1633) or ends (0) polling vote responses; becomePreCandidate / becomeCandidate reset
+// the votes (raft.go:784 via reset, :893-896).  StepWire then records the group's vote responses.
+func (b *BatchEngine) Campaign(group uint64, respType uint8) error {
+	if respType != 0 {
+		if err := hipErr(C.rafthip_reset_votes(b.e, C.uint64_t(group), 1)); err != nil {
+			return err
+		}
+	}
+	return hipErr(C.rafthip_upload_campaign(b.e, C.uint64_t(group), 1, (*C.uint8_t)(unsafe.Pointer(&respType))))
+}
+
+// TallyVotes: ProgressTracker.TallyVotes for every group (tracker/tracker.go:267-290); result[g] is
+// quorum.VoteResult (1 pending, 2 lost, 3 won).
+func (b *BatchEngine) TallyVotes(result []uint8) error {
+	if err := hipErr(C.rafthip_tally_votes(b.e)); err != nil {
+		return err
+	}
+	return hipErr(C.rafthip_read_vote_result(b.e, 0, C.uint64_t(len(result)), (*C.uint8_t)(unsafe.Pointer(&result[0])), nil, nil))
+}
+
 // MaybeCommit: raft.maybeCommit for every group (raft.go:755-758, log.go:447-456);
 // returns the groups whose raftLog.committed moved, sorted by group.
 func (b *BatchEngine) MaybeCommit(pairs []CommitPair) (int, error) {

@@ -78,7 +78,8 @@ def lib():
         L.oracle_message_unmarshal.argtypes = [vp, C.c_uint64, vp]
         L.oracle_step_wire_msgs.restype = None
         L.oracle_step_wire_msgs.argtypes = [C.c_uint64, C.c_int, vp, C.c_uint64, vp, vp, C.c_int, vp, C.c_uint64,
-                                            vp, vp, vp, vp, C.c_uint64, vp, vp, C.c_uint64, vp, vp, vp]
+                                            vp, vp, vp, vp, C.c_uint64, vp, vp, C.c_uint64, vp, vp, vp,
+                                            vp, vp, C.c_uint64]
         L.oracle_progress_new.restype = vp
         L.oracle_progress_new.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_uint64]
         L.oracle_progress_free.restype = None
@@ -108,7 +109,7 @@ def lib():
         L.oracle_record_votes.argtypes = [C.c_uint64, C.c_int, vp, C.c_uint64, vp, C.c_uint64]
         L.oracle_decode_wire_msgs.restype = None
         L.oracle_decode_wire_msgs.argtypes = [C.c_uint64, C.c_int, vp, C.c_uint64, vp, vp, vp, vp, C.c_uint64, vp, vp,
-                                              C.c_uint64, vp, vp, vp, vp]
+                                              C.c_uint64, vp, vp, vp, vp, vp, vp, C.c_uint64]
         L.oracle_batch_check_quorum.restype = None
         L.oracle_batch_check_quorum.argtypes = [C.c_uint64, C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp]
         L.oracle_batch_heartbeat_commit.restype = None
@@ -347,9 +348,20 @@ def message_unmarshal(data):
                "context": ctx, "nested": bool(m.nested)}
 
 
-def step_wire_msgs(match, active, acks, ids, term, read_ctx, read_ctx_len, data, offsets, groups):
-    """Serialized raftpb.Message values stepped in order on a leader; mutates match/active/acks.
-    ids [S][G] = ProgressMap key per slot.  Returns (out_msgs, out_status, counts[8])."""
+def _campaign_args(campaign, votes, S, G):
+    if campaign is None:
+        return None, None, 0
+    campaign = _chk(campaign, np.uint8)
+    votes = _chk(votes, np.uint8)
+    assert campaign.shape == (G,) and votes.shape == (S, G)
+    return _vp(campaign), _vp(votes), votes.strides[0]
+
+
+def step_wire_msgs(match, active, acks, ids, term, read_ctx, read_ctx_len, data, offsets, groups, campaign=None,
+                   votes=None):
+    """Serialized raftpb.Message values stepped in order; mutates match/active/acks (and votes [S][G] for the
+    groups whose campaign[g] names a vote response type).  ids [S][G] = ProgressMap key per slot.
+    Returns (out_msgs, out_status, counts[10])."""
     match = _chk(match, np.uint64)
     ids = _chk(ids, np.uint64)
     S, G = match.shape
@@ -361,12 +373,12 @@ def step_wire_msgs(match, active, acks, ids, term, read_ctx, read_ctx_len, data,
     data = _chk(np.ascontiguousarray(data), np.uint8)
     out_msgs = np.zeros(n, dtype=MSG_DTYPE)
     out_status = np.zeros(n, dtype=np.uint8)
-    counts = np.zeros(8, dtype=np.uint64)
+    counts = np.zeros(10, dtype=np.uint64)
     lib().oracle_step_wire_msgs(G, S, _vp(match), match.strides[0] // 8, _vp(_chk(active)), _vp(_chk(acks)),
                                 active.dtype.itemsize, _vp(ids), ids.strides[0] // 8, _vp(_chk(term, np.uint64)),
                                 _vp(_chk(read_ctx, np.uint64)), _vp(_chk(read_ctx_len, np.uint8)),
                                 _vp(data) if len(data) else None, len(data), _vp(offsets), _vp(groups), n,
-                                _vp(out_msgs), _vp(out_status), _vp(counts))
+                                _vp(out_msgs), _vp(out_status), _vp(counts), *_campaign_args(campaign, votes, S, G))
     return out_msgs, out_status, counts
 
 
@@ -378,9 +390,10 @@ def record_votes(votes, msgs):
     return int(lib().oracle_record_votes(G, S, _vp(votes), votes.strides[0], _vp(msgs), len(msgs)))
 
 
-def decode_wire_msgs(ids, term, read_ctx, read_ctx_len, data, offsets, groups):
-    """Decode + classify only: (records, aux = RejectHint of rejections, status, counts[9]).  A rejection
-    with LogTerm > 0 is status 8 and record type 0xFE (the host steps it)."""
+def decode_wire_msgs(ids, term, read_ctx, read_ctx_len, data, offsets, groups, campaign=None, votes=None):
+    """Decode + classify only: (records, aux = RejectHint of rejections, status, counts[10]).  A rejection
+    with LogTerm > 0 is status 8 and record type 0xFE (the host steps it).  Vote responses are polled into
+    votes as in step_wire_msgs."""
     ids = _chk(ids, np.uint64)
     S, G = ids.shape
     offsets = _chk(np.ascontiguousarray(offsets), np.uint64)
@@ -390,11 +403,12 @@ def decode_wire_msgs(ids, term, read_ctx, read_ctx_len, data, offsets, groups):
     out_msgs = np.zeros(n, dtype=MSG_DTYPE)
     aux = np.zeros(n, dtype=np.uint64)
     status = np.zeros(n, dtype=np.uint8)
-    counts = np.zeros(9, dtype=np.uint64)
+    counts = np.zeros(10, dtype=np.uint64)
     lib().oracle_decode_wire_msgs(G, S, _vp(ids), ids.strides[0] // 8, _vp(_chk(term, np.uint64)),
                                   _vp(_chk(read_ctx, np.uint64)), _vp(_chk(read_ctx_len, np.uint8)),
                                   _vp(data) if len(data) else None, len(data), _vp(offsets), _vp(groups), n,
-                                  _vp(out_msgs), _vp(aux), _vp(status), _vp(counts))
+                                  _vp(out_msgs), _vp(aux), _vp(status), _vp(counts),
+                                  *_campaign_args(campaign, votes, S, G))
     return out_msgs, aux, status, counts
 
 

@@ -872,6 +872,14 @@ ORACLE_API int oracle_message_unmarshal(const uint8_t *d, uint64_t l, oracle_pbm
  *   MsgHeartbeatResp with the pending ReadIndex context: recvAck (:1552,
  *   read_only.go:68-76).
  * ids is the ProgressMap key of each slot, [nslots][ids_stride], 0 = no row.
+ *
+ * With campaign != NULL the groups may also be campaigning: campaign[g] is
+ * stepCandidate's myVoteRespType (raft.go:1628-1633; 0 = not a candidate).  A
+ * MsgVoteResp (6) / MsgPreVoteResp (18) passes the term gate — a granted
+ * MsgPreVoteResp also with a higher term, raft.go:1068-1076 — and, when it is
+ * the group's own type and its sender has a row, is polled: RecordVote, first
+ * vote sticks (raft.go:1041-1049, tracker/tracker.go:260-265) -> status 9.
+ * The other type / a group that is not campaigning -> status 1.
  */
 static void wire_msgs(int apply, uint64_t G, int nslots, uint64_t *match, uint64_t stride,
                       void *active, void *acks, int mask_bytes, const uint64_t *ids,
@@ -879,8 +887,9 @@ static void wire_msgs(int apply, uint64_t G, int nslots, uint64_t *match, uint64
                       const uint64_t *read_ctx, const uint8_t *read_ctx_len,
                       const uint8_t *bytes, uint64_t nbytes, const uint64_t *offsets,
                       const uint32_t *groups, uint64_t n, oracle_msg *out_msgs, uint64_t *out_aux,
-                      uint8_t *out_status, uint64_t *counts) {
-    for (int k = 0; k < 9; k++) counts[k] = 0;
+                      uint8_t *out_status, uint64_t *counts, const uint8_t *campaign, uint8_t *votes,
+                      uint64_t votes_stride) {
+    for (int k = 0; k < 10; k++) counts[k] = 0;
     for (uint64_t i = 0; i < n; i++) {
         oracle_msg o = {groups[i], 0xFF, 0xFF, 0, 0, 0};
         oracle_pbmsg m;
@@ -899,14 +908,31 @@ static void wire_msgs(int apply, uint64_t G, int nslots, uint64_t *match, uint64
             o.reject = (uint8_t)m.reject;
             o.index = m.index;
             if (m.ctx_len > 0) o.flags |= 2;
-            if (m.type != 4 && m.type != 9) {
+            int vote = campaign != NULL && (m.type == 6 || m.type == 18);
+            if (m.type != 4 && m.type != 9 && !vote) {
                 st = 1;
             } else if (m.nested) {
                 st = 5;
-            } else if (m.term != 0 && m.term > term[g]) {
+            } else if (m.term != 0 && m.term > term[g] && !(m.type == 18 && !m.reject)) {
                 st = 4;
             } else if (m.term != 0 && m.term < term[g]) {
                 st = 3;
+            } else if (vote) {
+                if (campaign[g] == 0 || (uint32_t)m.type != campaign[g]) {
+                    st = 1; /* stepLeader / stepFollower / the other candidate state: ignored */
+                } else {
+                    int slot = -1;
+                    for (int s = 0; s < nslots && slot < 0; s++)
+                        if (m.from != 0 && ids[(uint64_t)s * ids_stride + g] == m.from) slot = s;
+                    if (slot < 0) {
+                        st = 2; /* recorded under an id nothing reads: neither result nor counts change */
+                    } else {
+                        st = 9;
+                        o.slot = (uint8_t)slot;
+                        uint8_t *cell = &votes[(uint64_t)slot * votes_stride + g];
+                        if (*cell == 0) *cell = m.reject ? 1 : 2; /* RecordVote */
+                    }
+                }
             } else {
                 int slot = -1;
                 for (int s = 0; s < nslots && slot < 0; s++) /* r.trk.Progress[m.From] */
@@ -961,23 +987,24 @@ ORACLE_API void oracle_step_wire_msgs(uint64_t G, int nslots, uint64_t *match, u
                                       const uint64_t *read_ctx, const uint8_t *read_ctx_len,
                                       const uint8_t *bytes, uint64_t nbytes, const uint64_t *offsets,
                                       const uint32_t *groups, uint64_t n, oracle_msg *out_msgs,
-                                      uint8_t *out_status, uint64_t *counts) {
-    uint64_t c9[9];
+                                      uint8_t *out_status, uint64_t *counts /* [10] */,
+                                      const uint8_t *campaign, uint8_t *votes, uint64_t votes_stride) {
     wire_msgs(1, G, nslots, match, stride, active, acks, mask_bytes, ids, ids_stride, term, read_ctx, read_ctx_len,
-              bytes, nbytes, offsets, groups, n, out_msgs, NULL, out_status, c9);
-    for (int k = 0; k < 8; k++) counts[k] = c9[k];
+              bytes, nbytes, offsets, groups, n, out_msgs, NULL, out_status, counts, campaign, votes, votes_stride);
 }
 
-/* The same decode and classification without stepping anything: the records (and, for
- * rejections, RejectHint as aux) that go on to the Progress stepper (oracle_step_progress). */
+/* The same decode and classification without stepping a Progress: the records (and, for
+ * rejections, RejectHint as aux) that go on to the Progress stepper (oracle_step_progress).
+ * Vote responses are polled here too (campaign != NULL). */
 ORACLE_API void oracle_decode_wire_msgs(uint64_t G, int nslots, const uint64_t *ids, uint64_t ids_stride,
                                         const uint64_t *term, const uint64_t *read_ctx,
                                         const uint8_t *read_ctx_len, const uint8_t *bytes, uint64_t nbytes,
                                         const uint64_t *offsets, const uint32_t *groups, uint64_t n,
                                         oracle_msg *out_msgs, uint64_t *out_aux, uint8_t *out_status,
-                                        uint64_t *counts /* [9] */) {
+                                        uint64_t *counts /* [10] */, const uint8_t *campaign, uint8_t *votes,
+                                        uint64_t votes_stride) {
     wire_msgs(0, G, nslots, NULL, 0, NULL, NULL, 1, ids, ids_stride, term, read_ctx, read_ctx_len, bytes, nbytes,
-              offsets, groups, n, out_msgs, out_aux, out_status, counts);
+              offsets, groups, n, out_msgs, out_aux, out_status, counts, campaign, votes, votes_stride);
 }
 
 /*

@@ -43,7 +43,7 @@ SYMBOLS = [
     "rafthip_progress_config", "rafthip_upload_progress", "rafthip_read_progress", "rafthip_upload_inflights",
     "rafthip_read_inflights", "rafthip_upload_first_index", "rafthip_step_progress", "rafthip_step_wire",
     "rafthip_merge_acks", "rafthip_host_alloc", "rafthip_host_free",
-    "rafthip_record_votes", "rafthip_read_votes", "rafthip_step_dense",
+    "rafthip_record_votes", "rafthip_read_votes", "rafthip_step_dense", "rafthip_upload_campaign",
 ]
 MSG_VOTE_RESP, MSG_PRE_VOTE_RESP = 6, 18
 
@@ -53,9 +53,9 @@ ACT_SEND_APPEND, ACT_UPDATED, ACT_WAS_PAUSED, ACT_CAUGHT_UP, ACT_ERROR, ACT_DEFE
 STEP_LIMIT = 64
 
 
-WIRE_STATUSES = 9
+WIRE_STATUSES = 10
 (WIRE_APPLIED, WIRE_OTHER_TYPE, WIRE_NO_PROGRESS, WIRE_STALE_TERM, WIRE_HIGHER_TERM, WIRE_NESTED, WIRE_MALFORMED,
- WIRE_BAD_GROUP, WIRE_NEEDS_LOG) = range(9)
+ WIRE_BAD_GROUP, WIRE_NEEDS_LOG, WIRE_VOTE) = range(10)
 MSG_NEEDS_HOST = 0xFE
 MSGF_READ_CTX, MSGF_HAS_CTX = 1, 2
 
@@ -159,6 +159,7 @@ def load_library():
         "rafthip_upload_ids": (i32, [vp, u64, u64, vp, u64]),
         "rafthip_upload_term": (i32, [vp, u64, u64, vp]),
         "rafthip_upload_read_ctx": (i32, [vp, u64, u64, vp, vp]),
+        "rafthip_upload_campaign": (i32, [vp, u64, u64, vp]),
         "rafthip_ingest_wire": (i32, [vp, vp, vp, vp, u64, vp, vp, vp]),
         "rafthip_progress_config": (i32, [vp, u32, u64]),
         "rafthip_upload_progress": (i32, [vp, u64, u64, vp, vp, vp, u64]),
@@ -395,8 +396,13 @@ class Engine:
         first, count = self._range(first, count)
         _check(self._L.rafthip_upload_read_ctx(self._h, first, count, _ptr(ctx), _ptr(ctx_len)))
 
+    def upload_campaign(self, resp_type, first=0, count=None):
+        """resp_type u8 per group: MSG_PRE_VOTE_RESP / MSG_VOTE_RESP / 0; None clears every group."""
+        first, count = self._range(first, count)
+        _check(self._L.rafthip_upload_campaign(self._h, first, count, _ptr(resp_type)))
+
     def ingest_wire(self, data, offsets, groups, n=None, want_msgs=True, want_status=True, want_counts=True):
-        """Serialized raftpb.Message values -> (out_msgs, out_status, counts[8]); data / offsets / groups
+        """Serialized raftpb.Message values -> (out_msgs, out_status, counts[WIRE_STATUSES]); data / offsets / groups
         are numpy arrays or raw device pointers (then pass n)."""
         if n is None:
             n = len(groups)
@@ -460,7 +466,7 @@ class Engine:
         return actions
 
     def step_wire(self, data, offsets, groups, n=None):
-        """Serialized messages -> (decoded records, status, counts[9], action bytes) through the Progress stepper."""
+        """Serialized messages -> (decoded records, status, counts[WIRE_STATUSES], action bytes) through the Progress stepper."""
         if n is None:
             n = len(groups)
         msgs = np.zeros(n, dtype=MSG_DTYPE)

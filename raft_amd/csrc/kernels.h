@@ -797,7 +797,7 @@ __global__ __launch_bounds__(kBlock) void k_record_votes(uint8_t* __restrict__ v
     }
     if (PASS == 1) {
         const u64 b = __ballot(bad);
-        if (b != 0 && (threadIdx.x & 63) == 0) atomicAdd(dropped, (u64)__popcll(b));
+        if (dropped != nullptr && b != 0 && (threadIdx.x & 63) == 0) atomicAdd(dropped, (u64)__popcll(b));
     }
 }
 

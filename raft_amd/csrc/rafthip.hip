@@ -23,7 +23,7 @@ static_assert(kWireApplied == RAFTHIP_WIRE_APPLIED && kWireOtherType == RAFTHIP_
                   kWireNoProgress == RAFTHIP_WIRE_NO_PROGRESS && kWireStaleTerm == RAFTHIP_WIRE_STALE_TERM &&
                   kWireHigherTerm == RAFTHIP_WIRE_HIGHER_TERM && kWireNested == RAFTHIP_WIRE_NESTED &&
                   kWireMalformed == RAFTHIP_WIRE_MALFORMED && kWireBadGroup == RAFTHIP_WIRE_BAD_GROUP &&
-                  kWireNeedsLog == RAFTHIP_WIRE_NEEDS_LOG && kEvNeedsHost == RAFTHIP_MSG_NEEDS_HOST &&
+                  kWireNeedsLog == RAFTHIP_WIRE_NEEDS_LOG && kWireVote == RAFTHIP_WIRE_VOTE && kEvNeedsHost == RAFTHIP_MSG_NEEDS_HOST &&
                   kWireStatuses == RAFTHIP_WIRE_STATUSES && kMsgFlagHasCtx == RAFTHIP_MSGF_HAS_CTX &&
                   kWireNoSlot == RAFTHIP_WIRE_NO_SLOT,
               "wire constants");
@@ -113,6 +113,7 @@ struct rafthip_engine {
     // wire ingest
     u64* wire_hdr = nullptr;       // [G][H] per group: r.Term, pending ReadIndex ctx, its length, raft id per slot (wire.h)
     bool have_ids = false, have_term = false;
+    bool campaigning = false;  // rafthip_upload_campaign named a vote response type for some group
     u64* d_wire_counts = nullptr;  // [RAFTHIP_WIRE_STATUSES]
     // growable staging: wire bytes, offsets, groups, out msgs, out status; progress aux, actions, prev links
     void* stage_buf[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -1025,7 +1026,7 @@ int rafthip_upload_term(rafthip_engine* e, uint64_t first, uint64_t count, const
     if ((rc = device_view(e, term, count * 8, &tmp, &d_term))) return rc;
     hipLaunchKernelGGL(k_hdr_set_field, dim3((u32)((count + kBlock - 1) / kBlock)), dim3(kBlock), 0, e->stream,
                        static_cast<const u64*>(d_term), static_cast<const uint8_t*>(nullptr), (u64)count, H, kHdrTerm,
-                       0u, e->wire_hdr + first * H);
+                       0u, 0u, e->wire_hdr + first * H);
     if ((rc = finish_and_free(e, tmp, nullptr))) return rc;
     e->stats.bytes_uploaded += count * 8;
     return RAFTHIP_OK;
@@ -1049,9 +1050,43 @@ int rafthip_upload_read_ctx(rafthip_engine* e, uint64_t first, uint64_t count, c
     }
     hipLaunchKernelGGL(k_hdr_set_field, dim3((u32)((count + kBlock - 1) / kBlock)), dim3(kBlock), 0, e->stream,
                        static_cast<const u64*>(d_ctx), static_cast<const uint8_t*>(d_len), (u64)count, H, kHdrCtx,
-                       kHdrCtxLen, e->wire_hdr + first * H);
+                       kHdrCtxLen, 0u, e->wire_hdr + first * H);
     if ((rc = finish_and_free(e, tmp, tmp8))) return rc;
     e->stats.bytes_uploaded += count * 9;
+    return RAFTHIP_OK;
+}
+
+int rafthip_upload_campaign(rafthip_engine* e, uint64_t first, uint64_t count, const uint8_t* resp_type) {
+    int rc = check_range(e, first, count);
+    if (rc) return rc;
+    DeviceGuard guard(e->device);
+    if ((rc = ensure_wire_hdr(e))) return rc;
+    if (!resp_type) {  // nobody campaigns any more: the wire path skips the vote passes again
+        if (first != 0 || count != e->G) return fail(RAFTHIP_EINVAL, "resp_type NULL clears every group: pass the whole range");
+        e->campaigning = false;
+    }
+    if (count == 0) return RAFTHIP_OK;
+    const u32 H = wire_hdr_words(e->S);
+    void* tmp = nullptr;
+    const void* d_type = nullptr;
+    if ((rc = ensure(e, e->votes, (size_t)e->S * e->stride))) return rc;
+    if ((rc = ensure(e, e->vote_first, (size_t)e->S * e->stride * sizeof(u32)))) return rc;
+    if (resp_type) {
+        if ((rc = device_view(e, resp_type, count, &tmp, &d_type))) return rc;
+    } else {
+        HIP_TRY(hipMalloc(&tmp, count));
+        if (hipError_t err = hipMemsetAsync(tmp, 0, count, e->stream)) {
+            (void)hipFree(tmp);
+            return fail(RAFTHIP_EIO, "hipMemsetAsync: %s", hipGetErrorString(err));
+        }
+        d_type = tmp;
+    }
+    hipLaunchKernelGGL(k_hdr_set_field, dim3((u32)((count + kBlock - 1) / kBlock)), dim3(kBlock), 0, e->stream,
+                       static_cast<const u64*>(nullptr), static_cast<const uint8_t*>(d_type), (u64)count, H, 0u,
+                       kHdrCtxLen, kHdrCampaignShift, e->wire_hdr + first * H);
+    if ((rc = finish_and_free(e, tmp, nullptr))) return rc;
+    if (resp_type) e->campaigning = true;
+    e->stats.bytes_uploaded += resp_type ? count : 0;
     return RAFTHIP_OK;
 }
 
@@ -1066,7 +1101,8 @@ static int wire_run(rafthip_engine* e, const uint8_t* bytes, const uint64_t* off
                     uint8_t* actions) {
     if (!e) return fail(RAFTHIP_EINVAL, "engine is NULL");
     if (to_progress && !e->prog) return fail(RAFTHIP_EINVAL, "rafthip_progress_config must come first");
-    if (to_progress && n > (1ull << 31)) return fail(RAFTHIP_EINVAL, "more than 2^31 events in one batch: split it");
+    if ((to_progress || e->campaigning) && n > (1ull << 31))
+        return fail(RAFTHIP_EINVAL, "more than 2^31 events in one batch: split it");
     if (status_counts) memset(status_counts, 0, RAFTHIP_WIRE_STATUSES * sizeof(uint64_t));
     if (n == 0) return RAFTHIP_OK;
     if (!offsets || !groups) return fail(RAFTHIP_EINVAL, "offsets/groups is NULL");
@@ -1101,7 +1137,7 @@ static int wire_run(rafthip_engine* e, const uint8_t* bytes, const uint64_t* off
     const bool status_host = out_status && !is_device_ptr(out_status);
     if (out_msgs && !msgs_host) {
         d_msgs = reinterpret_cast<Msg*>(out_msgs);
-    } else if (out_msgs || to_progress) {
+    } else if (out_msgs || to_progress || e->campaigning) {
         if ((rc = stage_reserve(e, 3, (size_t)n * sizeof(Msg)))) return rc;
         d_msgs = static_cast<Msg*>(e->stage_buf[3]);
     }
@@ -1142,6 +1178,19 @@ static int wire_run(rafthip_engine* e, const uint8_t* bytes, const uint64_t* off
         HIP_TRY(hipGetLastError());
     }
     if (to_progress && (rc = progress_passes(e, d_msgs, d_aux, n, d_act, true))) return rc;
+    if (e->campaigning) {
+        // RecordVote for the vote responses the decode let through (status VOTE; every other vote
+        // response left the kernel without a slot), first vote per peer in stream order
+        const u32 blocks = (u32)((n + kBlock - 1) / kBlock);
+        u64* const no_count = nullptr;
+        hipLaunchKernelGGL(k_record_votes<1>, dim3(blocks), dim3(kBlock), 0, e->stream, e->votes, e->vote_first,
+                           e->stride, e->G, e->S, d_msgs, (u32)n, no_count);
+        hipLaunchKernelGGL(k_record_votes<2>, dim3(blocks), dim3(kBlock), 0, e->stream, e->votes, e->vote_first,
+                           e->stride, e->G, e->S, d_msgs, (u32)n, no_count);
+        hipLaunchKernelGGL(k_record_votes<3>, dim3(blocks), dim3(kBlock), 0, e->stream, e->votes, e->vote_first,
+                           e->stride, e->G, e->S, d_msgs, (u32)n, no_count);
+        HIP_TRY(hipGetLastError());
+    }
     bool wait = d_bytes != bytes || d_off != offsets || d_groups != groups || e->zero_copy_pending;  // caller may reuse its host buffers
     e->zero_copy_pending = false;
     if (msgs_host) {

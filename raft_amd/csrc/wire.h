@@ -29,7 +29,8 @@ enum : uint8_t {  // = RAFTHIP_WIRE_*
     kWireMalformed = 6,
     kWireBadGroup = 7,
     kWireNeedsLog = 8,  // rafthip_step_wire only
-    kWireStatuses = 9,
+    kWireVote = 9,      // a vote response of the group's own campaign: recorded (rafthip_upload_campaign)
+    kWireStatuses = 10,
 };
 constexpr uint8_t kEvNeedsHost = 0xFE;  // record type of a kWireNeedsLog message (progress.h)
 constexpr uint8_t kMsgFlagHasCtx = 2;
@@ -169,7 +170,10 @@ __device__ bool wire_parse(const R& rd, i64 pos, i64 end, WireFields& f) {
 // rounded up to 4 words (32-byte aligned rows): [term][ctx][ctx_len][ids...].
 // A decoded message gathers its term, its sender's slot and the pending
 // ReadIndex context from one or two lines instead of five.
+// Word 2 packs two bytes: bits 0-7 the length of the pending ReadIndex context, bits 8-15 the vote
+// response type the group's campaign counts (0 = not campaigning).
 constexpr u32 kHdrTerm = 0, kHdrCtx = 1, kHdrCtxLen = 2, kHdrIds = 3;
+constexpr u32 kHdrCampaignShift = 8;
 __host__ __device__ __forceinline__ u32 wire_hdr_words(u32 S) { return (kHdrIds + S + 3u) & ~3u; }
 
 __global__ __launch_bounds__(kWireBlock) void k_ingest_wire(
@@ -237,17 +241,39 @@ __global__ __launch_bounds__(kWireBlock) void k_ingest_wire(
             rec_type = f.type <= 0xFFu ? f.type : 0xFFu;
             if (f.ctx_len > 0) flags |= kMsgFlagHasCtx;
             const bool app = f.type == kMsgAppResp, hb = f.type == kMsgHeartbeatResp;
-            if (!app && !hb) {
+            const bool vote = f.type == kMsgVoteResp || f.type == kMsgPreVoteResp;
+            if (!app && !hb && !vote) {
                 status = kWireOtherType;
             } else if (f.nested) {
                 status = kWireNested;
             } else {
                 const u64* row = hdr + (u64)group * H;  // one or two lines hold all the group's lookup state
                 const u64 term = row[kHdrTerm];
-                if (f.term != 0 && f.term > term) {
+                // raft.go:1068-1076: a granted MsgPreVoteResp carries the pre-candidate's future term and does
+                // not make it a follower
+                if (f.term != 0 && f.term > term && !(f.type == kMsgPreVoteResp && !f.reject)) {
                     status = kWireHigherTerm;
                 } else if (f.term != 0 && f.term < term) {
                     status = kWireStaleTerm;
+                } else if (vote) {
+                    // stepCandidate, raft.go:1628-1648: only the response type of the campaign in progress is
+                    // polled; leaders, followers and the other candidate state ignore it
+                    const u32 mine = (u32)(row[kHdrCtxLen] >> kHdrCampaignShift) & 0xFFu;
+                    if (mine == 0 || f.type != mine) {
+                        status = kWireOtherType;
+                    } else {
+                        if (f.from != 0) {
+                            for (u32 s = 0; s < S; ++s) {
+                                if (row[kHdrIds + s] == f.from) {
+                                    slot = s;
+                                    break;
+                                }
+                            }
+                        }
+                        // a vote from an id without a row can change neither the result (config members
+                        // only, majority.go:188-197) nor the counts (tracker.go:274-287)
+                        status = slot == kWireNoSlot ? kWireNoProgress : kWireVote;
+                    }
                 } else {
                     if (f.from != 0) {
                         for (u32 s = 0; s < S; ++s) {
@@ -276,7 +302,7 @@ __global__ __launch_bounds__(kWireBlock) void k_ingest_wire(
                                 atomicMax(match + (u64)slot * stride + group, f.index);  // :1477
                             }
                         } else {
-                            const u64 want = row[kHdrCtxLen];
+                            const u64 want = row[kHdrCtxLen] & 0xFFu;
                             if (want != 0 && f.ctx_len == want && f.ctx == row[kHdrCtx]) {
                                 flags |= kMsgFlagCtx;
                                 if (apply) or_slot_bit(acks, mbytes, group, slot);  // read_only.go:68-76
@@ -296,7 +322,7 @@ __global__ __launch_bounds__(kWireBlock) void k_ingest_wire(
         if (out_status) out_status[i] = status;
         if (out_aux) {
             out_aux[i] = aux;
-            if (slot != kWireNoSlot) {  // applied or needs-log: an event of Progress (slot, group)
+            if (slot != kWireNoSlot && status != kWireVote) {  // applied or needs-log: an event of Progress (slot, group)
                 const u32 li = index_base + (u32)i;
                 prev[li] = atomicExch(&rec[(u64)slot * stride + group].head, li + 1);
                 actions[li] = kActDeferred;
@@ -319,12 +345,15 @@ __global__ __launch_bounds__(kBlock) void k_hdr_set_ids(const u64* __restrict__ 
 }
 // One word (and optionally a byte-wide second field) per group -> its row.
 __global__ __launch_bounds__(kBlock) void k_hdr_set_field(const u64* __restrict__ src, const uint8_t* __restrict__ src8,
-                                                          u64 count, u32 H, u32 field, u32 field8,
+                                                          u64 count, u32 H, u32 field, u32 field8, u32 shift8,
                                                           u64* __restrict__ hdr) {
     const u64 g = (u64)blockIdx.x * kBlock + threadIdx.x;
     if (g >= count) return;
-    hdr[g * H + field] = src[g];
-    if (src8) hdr[g * H + field8] = src8[g];
+    if (src) hdr[g * H + field] = src[g];
+    if (src8) {  // one byte of word field8, at bit `shift8`
+        u64& w = hdr[g * H + field8];
+        w = (w & ~((u64)0xFFu << shift8)) | ((u64)src8[g] << shift8);
+    }
 }
 
 }  // namespace rafthip

@@ -46,7 +46,7 @@ def run_both(oracle, e, state, data, offsets, groups, device_inputs=False):
     else:
         msgs, status, counts = e.ingest_wire(data, offsets, groups)
     assert np.array_equal(status, want_status)
-    assert np.array_equal(counts[:8], want_counts) and counts[8] == 0
+    assert np.array_equal(counts, want_counts) and counts[8] == 0 and counts[9] == 0
     assert np.array_equal(msgs, want_msgs)
     assert np.array_equal(e.read_match(), wm)
     assert np.array_equal(e.read_active(), wa)
@@ -63,7 +63,7 @@ def test_ingest_wire_random_batches(oracle, S, device_inputs):
     data, offsets = wu.pack(msgs)
     with raft_amd.Engine(G, S) as e:
         counts = run_both(oracle, e, state, data, offsets, groups, device_inputs)
-        assert counts.sum() == n and (counts > 0).all()
+        assert counts.sum() == n and (counts[:8] > 0).all()
         assert e.stats()["msgs_ingested"] == n
 
 
@@ -170,7 +170,7 @@ def test_ingest_wire_then_commit_full_size(oracle):
         e.upload_term(term)
         e.upload_read_ctx(cw, cl)
         _, status, counts = e.ingest_wire(data, offsets, groups, want_msgs=False)
-        assert np.array_equal(counts[:8], want_counts) and np.array_equal(status, want_status)
+        assert np.array_equal(counts, want_counts) and np.array_equal(status, want_status)
         assert counts[capi.WIRE_APPLIED] > 0.8 * n
         e.commit()
         assert np.array_equal(e.read_match(), wm)
@@ -245,3 +245,137 @@ def test_step_wire_feeds_the_progress_stepper(oracle, S, cap):
         w2 = po.step_progress(pl, cap, 0, active, acks, last, first, redo, np.ascontiguousarray(want_aux[idx]))
         assert np.array_equal(a2, w2) and (w2 & capi.ACT_DEFERRED == 0).all()
         assert np.array_equal(e.read_progress()["next"], pl["next"])
+
+
+class EngineVoteDriver:
+    """tests/golden/scenarios.json's wire_vote_sequences on the engine: the scenario's group sits among G others."""
+
+    def __init__(self, e, voters, G, g):
+        self.e, self.voters, self.G, self.g = e, voters, G, g
+        S = len(voters)
+        ids = np.zeros((S, G), dtype=np.uint64)
+        ids[:, g] = voters
+        e.set_uniform_config(S)
+        e.upload_ids(ids)
+        e.upload_term(np.zeros(G, dtype=np.uint64))
+        e.upload_read_ctx(np.zeros(G, dtype=np.uint64), np.zeros(G, dtype=np.uint8))
+        e.upload_campaign(np.zeros(G, dtype=np.uint8))
+
+    def become(self, resp_type, term):
+        self.e.upload_campaign(np.array([resp_type], dtype=np.uint8), first=self.g, count=1)
+        self.e.upload_term(np.array([term], dtype=np.uint64), first=self.g, count=1)
+        self.e.reset_votes(first=self.g, count=1)
+
+    def record(self, pairs):
+        m = np.zeros(len(pairs), dtype=capi.MSG_DTYPE)
+        m["group"], m["type"] = self.g, capi.MSG_VOTE_RESP
+        m["slot"] = [self.voters.index(i) for i, _ in pairs]
+        m["reject"] = [0 if v else 1 for _, v in pairs]
+        self.e.record_votes(m)
+
+    def wire(self, blob):
+        data, offsets = wu.pack([blob])
+        msgs, status, counts = self.e.ingest_wire(data, offsets, np.array([self.g], dtype=np.uint32))
+        assert counts[status[0]] == 1 and counts.sum() == 1
+        assert (msgs["slot"][0] != 0xFF) == (status[0] in (capi.WIRE_APPLIED, capi.WIRE_VOTE))
+        return int(status[0])
+
+    def tally(self):
+        self.e.tally_votes()
+        res, gr, rj = self.e.read_vote_result(first=self.g, count=1)
+        return int(res[0]), int(gr[0]), int(rj[0])
+
+
+def test_vote_responses_from_the_reference_transcripts():
+    from test_wire_cpu import _vote_sequences
+    for seq in _vote_sequences():
+        with raft_amd.Engine(70, len(seq["voters"])) as e:
+            drv = EngineVoteDriver(e, seq["voters"], 70, 41)
+            wu.replay_vote_sequence(seq, drv)
+            votes = e.read_votes()
+            votes[:, 41] = 0
+            assert not votes.any()  # no other group's cells moved
+
+
+def test_figure7_election_from_the_wire():
+    import figure7_util as f7
+    fx = f7.load()
+    with raft_amd.Engine(9, len(fx["voters"])) as e:
+        drv = EngineVoteDriver(e, fx["voters"], 9, 4)
+        drv.become(wu.MSG_VOTE_RESP, fx["term"])
+        for v in fx["votes"]:
+            if v["from"] == fx["leader"]:
+                drv.record([(v["from"], v["granted"])])
+            else:
+                blob = wu.encode_message(type=wu.MSG_VOTE_RESP, to=fx["leader"], frm=v["from"], term=fx["term"],
+                                         reject=not v["granted"])
+                assert drv.wire(blob) == capi.WIRE_VOTE
+            assert drv.tally() == (wu.VOTE_RESULT[v["result"]], v["granted_total"], v["rejected_total"]), v
+
+
+@pytest.mark.parametrize("S,to_progress", [(3, False), (5, True), (9, False), (16, True), (33, False), (64, True)])
+def test_vote_wire_random_batches(oracle, S, to_progress):
+    """Candidates, pre-candidates, leaders and followers side by side: vote responses and MsgAppResp in one batch,
+    through rafthip_ingest_wire and through rafthip_step_wire; status, records, counts, vote cells, tallies and the
+    leaders' planes against the oracle stepping the same bytes one message at a time."""
+    import progress_util as pu
+    from oracle import pyoracle as po
+    rng = np.random.default_rng(2100 + S)
+    G, n = 613, 25000
+    ids, term, ctxs, match, active, acks = make_state(rng, S, G)
+    term += np.uint64(1)
+    campaign = rng.choice(np.array([0, 6, 18], dtype=np.uint8), size=G, p=[0.3, 0.35, 0.35])
+    votes = rng.choice(np.array([0, 1, 2], dtype=np.uint8), size=(S, G), p=[0.8, 0.1, 0.1])
+    blobs, groups = wu.random_vote_batch(rng, n, G, ids, term)
+    data, offsets = wu.pack(blobs)
+    cw, cl = wu.ctx_words(ctxs)
+    in_mask = np.full(G, (1 << min(S, 7)) - 1, dtype=gu.mask_dtype(S))
+    with raft_amd.Engine(G, S) as e:
+        e.upload_config(in_mask, np.zeros_like(in_mask))
+        e.upload_match(match)
+        e.upload_active(active)
+        e.upload_acks(acks)
+        e.upload_ids(ids)
+        e.upload_term(term)
+        e.upload_read_ctx(cw, cl)
+        e.upload_votes(votes)
+        e.upload_campaign(campaign)
+        wv = votes.copy()
+        if to_progress:
+            pl = pu.random_planes(rng, S, G, 4, 0)
+            pl["match"] = match.copy()
+            pl["next"] = np.maximum(pl["next"], match + np.uint64(1))
+            last = match.max(axis=0) + np.uint64(1 << 31)
+            first = np.zeros(G, dtype=np.uint64)
+            e.progress_config(4, 0)
+            e.upload_progress(pl["pstate"], pl["next"], pl["pending"])
+            e.upload_inflights(pl["infl_meta"], pl["infl_bytes"], pl["ring_index"], pl["ring_bytes"])
+            e.upload_term_range(np.zeros(G, dtype=np.uint64), last)
+            e.upload_first_index(first)
+            want_msgs, want_aux, want_status, want_counts = oracle.decode_wire_msgs(ids, term, cw, cl, data, offsets, groups,
+                                                                                    campaign=campaign, votes=wv)
+            msgs, status, counts, act = e.step_wire(data, offsets, groups)
+            ev = want_msgs.copy()
+            ev["slot"][want_status == capi.WIRE_VOTE] = 0xFF  # a vote response is no event of a Progress
+            want_act = po.step_progress(pl, 4, 0, active, acks, last, first, ev, want_aux)
+            assert np.array_equal(act, want_act)
+            assert (act[want_status == capi.WIRE_VOTE] == capi.ACT_DROPPED).all()
+            assert np.array_equal(e.read_progress()["next"], pl["next"]) and np.array_equal(e.read_match(), pl["match"])
+        else:
+            wm, wa, wk = match.copy(), active.copy(), acks.copy()
+            want_msgs, want_status, want_counts = oracle.step_wire_msgs(wm, wa, wk, ids, term, cw, cl, data, offsets, groups,
+                                                                        campaign=campaign, votes=wv)
+            msgs, status, counts = e.ingest_wire(data, offsets, groups)
+            assert np.array_equal(e.read_match(), wm) and np.array_equal(e.read_active(), wa)
+        assert np.array_equal(status, want_status) and np.array_equal(counts, want_counts)
+        assert np.array_equal(msgs, want_msgs)
+        assert counts[capi.WIRE_VOTE] > n // 10 and counts[capi.WIRE_HIGHER_TERM] > 0 and counts[capi.WIRE_OTHER_TYPE] > 0
+        assert np.array_equal(e.read_votes(), wv) and (wv != votes).any()
+        e.tally_votes()
+        res, gr, rj = e.read_vote_result()
+        wres, wgr, wrj = oracle.batch_tally_votes(wv, in_mask, np.zeros_like(in_mask))
+        assert np.array_equal(res, wres) and np.array_equal(gr, wgr) and np.array_equal(rj, wrj)
+        # clearing the campaign plane turns the vote passes off: the same bytes now leave the cells alone
+        e.upload_campaign(None)
+        _, status2, counts2 = e.ingest_wire(data, offsets, groups)
+        assert counts2[capi.WIRE_VOTE] == 0 and np.array_equal(e.read_votes(), wv)

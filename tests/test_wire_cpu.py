@@ -136,8 +136,8 @@ def test_step_wire_equals_stepping_the_decoded_records(oracle):
     cw, cl = wu.ctx_words(ctxs)
     m1, a1, k1 = match.copy(), active.copy(), acks.copy()
     out, status, counts = oracle.step_wire_msgs(m1, a1, k1, ids, term, cw, cl, data, offsets, groups)
-    assert counts.sum() == n and all(counts > 0), counts  # every class is exercised
-    assert np.array_equal(np.bincount(status, minlength=8), counts.astype(np.int64))
+    assert counts.sum() == n and all(counts[:8] > 0), counts  # every class is exercised
+    assert np.array_equal(np.bincount(status, minlength=10), counts.astype(np.int64))
     applied = out[status == 0]
     assert (applied["slot"] < S).all() and (out["slot"][status != 0] == 0xFF).all()
     # the ids the applied records resolved to are the senders
@@ -192,3 +192,105 @@ def test_vectorised_encoder_decodes_like_the_scalar_one(oracle):
                                       reject=got["reject"], context=got["context"])
         kinds.add((got["type"], got["context"] is not None, got["reject"]))
     assert len(kinds) >= 4
+
+
+class OracleVoteDriver:
+    """One group of tests/golden/scenarios.json's wire_vote_sequences on the oracle."""
+
+    def __init__(self, oracle, voters):
+        self.o, self.voters = oracle, voters
+        S = len(voters)
+        self.ids = np.array(voters, dtype=np.uint64).reshape(S, 1)
+        self.votes = np.zeros((S, 1), dtype=np.uint8)
+        self.campaign = np.zeros(1, dtype=np.uint8)
+        self.term = np.zeros(1, dtype=np.uint64)
+        self.match = np.zeros((S, 1), dtype=np.uint64)
+        self.bits = (np.zeros(1, dtype=np.uint8), np.zeros(1, dtype=np.uint8))
+
+    def become(self, resp_type, term):
+        self.campaign[0], self.term[0] = resp_type, term
+        self.votes[:] = 0
+
+    def record(self, pairs):
+        for i, v in pairs:
+            cell = self.votes[self.voters.index(i)]
+            if cell[0] == 0:
+                cell[0] = 2 if v else 1
+
+    def wire(self, blob):
+        data, offsets = wu.pack([blob])
+        z = np.zeros(1, dtype=np.uint64)
+        before = self.votes.copy()
+        out, status, counts = self.o.step_wire_msgs(self.match, self.bits[0], self.bits[1], self.ids, self.term, z,
+                                                    np.zeros(1, dtype=np.uint8), data, offsets, np.zeros(1, dtype=np.uint32),
+                                                    campaign=self.campaign, votes=self.votes)
+        assert counts[status[0]] == 1 and counts.sum() == 1
+        if status[0] != 9:
+            assert np.array_equal(self.votes, before) and out["slot"][0] == 0xFF
+        assert not self.match.any() and not self.bits[0].any()  # a vote response touches no Progress
+        return int(status[0])
+
+    def tally(self):
+        res, gr, rj = self.o.batch_tally_votes(self.votes, uniform_voters=len(self.voters))
+        return int(res[0]), int(gr[0]), int(rj[0])
+
+
+def _vote_sequences():
+    import json
+    import os
+    with open(os.path.join(gu.HERE, "golden", "scenarios.json")) as fh:
+        return json.load(fh)["wire_vote_sequences"]
+
+
+def test_vote_responses_from_the_reference_transcripts(oracle):
+    """testdata/prevote.txt and forget_leader_prevote_checkquorum.txt: which vote responses a (pre-)candidate polls
+    (raft.go:1068-1076 term gate, :1628-1648 myVoteRespType) and the tallies it logged after each."""
+    for seq in _vote_sequences():
+        wu.replay_vote_sequence(seq, OracleVoteDriver(oracle, seq["voters"]))
+
+
+def test_figure7_election_from_the_wire(oracle):
+    """The election of testdata/probe_and_replicate.txt:381-468 with every response as serialized bytes."""
+    import figure7_util as f7
+    fx = f7.load()
+    drv = OracleVoteDriver(oracle, fx["voters"])
+    drv.become(wu.MSG_VOTE_RESP, fx["term"])
+    for v in fx["votes"]:
+        if v["from"] == fx["leader"]:
+            drv.record([(v["from"], v["granted"])])
+        else:
+            blob = wu.encode_message(type=wu.MSG_VOTE_RESP, to=fx["leader"], frm=v["from"], term=fx["term"],
+                                     reject=not v["granted"])
+            assert drv.wire(blob) == 9
+        assert drv.tally() == (wu.VOTE_RESULT[v["result"]], v["granted_total"], v["rejected_total"]), v
+
+
+def test_vote_wire_gates(oracle):
+    """Every branch around a vote response: term gate before the type test, the pre-vote exception only for
+    grants, the other response type, unknown senders, first vote sticks, nothing without a campaign plane."""
+    drv = OracleVoteDriver(oracle, [1, 2, 3])
+    enc = lambda **kw: wu.encode_message(to=1, **kw)
+    drv.become(wu.MSG_PRE_VOTE_RESP, 5)
+    assert drv.wire(enc(type=18, frm=2, term=6, reject=True)) == 4    # higher-term rejection: becomeFollower, the host's
+    assert drv.wire(enc(type=18, frm=2, term=9, reject=False)) == 9   # a grant passes with any higher term
+    assert drv.wire(enc(type=18, frm=2, term=5, reject=True)) == 9    # polled, but the first vote sticks
+    assert drv.tally() == (1, 1, 0)
+    assert drv.wire(enc(type=18, frm=3, term=4, reject=False)) == 3   # stale
+    assert drv.wire(enc(type=6, frm=3, term=5, reject=False)) == 1    # a MsgVoteResp while pre-campaigning
+    assert drv.wire(enc(type=6, frm=3, term=6, reject=False)) == 4    # ... with a higher term: step down first
+    assert drv.wire(enc(type=18, frm=7, term=5, reject=False)) == 2   # no row for the sender
+    assert drv.wire(enc(type=18, frm=0, term=5, reject=False)) == 2
+    assert drv.wire(enc(type=18, frm=3, term=0, reject=True)) == 9    # Term 0: local message, no gate (raft.go:1054)
+    assert drv.tally() == (1, 1, 1)
+    drv.become(wu.MSG_VOTE_RESP, 6)
+    assert drv.wire(enc(type=18, frm=2, term=7, reject=False)) == 1   # the pre-vote exception passes the gate, the type does not match
+    assert drv.wire(enc(type=6, frm=2, term=6, reject=True)) == 9 and drv.wire(enc(type=6, frm=3, term=6, reject=True)) == 9
+    assert drv.tally() == (2, 0, 2)  # VoteLost
+    drv.become(0, 6)
+    assert drv.wire(enc(type=6, frm=2, term=6, reject=False)) == 1
+    # without a campaign plane vote responses are simply not this path's
+    data, offsets = wu.pack([enc(type=6, frm=2, term=6)])
+    z = np.zeros(1, dtype=np.uint64)
+    _, status, _ = oracle.step_wire_msgs(drv.match, drv.bits[0], drv.bits[1], drv.ids, drv.term, z, np.zeros(1, dtype=np.uint8),
+                                         data, offsets, np.zeros(1, dtype=np.uint32))
+    assert status[0] == 1

@@ -263,3 +263,46 @@ def encode_responses(rng, frm, term, index, ctx8, app_frac=0.6):
     offsets = np.zeros(n + 1, dtype=np.uint64)
     np.cumsum(keep.sum(axis=1), out=offsets[1:])
     return np.ascontiguousarray(M[keep]), offsets
+
+
+MSG_VOTE_RESP, MSG_PRE_VOTE_RESP = 6, 18
+MSG_TYPES = {"MsgAppResp": MSG_APP_RESP, "MsgHeartbeatResp": MSG_HEARTBEAT_RESP, "MsgVoteResp": MSG_VOTE_RESP,
+             "MsgPreVoteResp": MSG_PRE_VOTE_RESP}
+CAMPAIGN_OF = {"StatePreCandidate": MSG_PRE_VOTE_RESP, "StateCandidate": MSG_VOTE_RESP, "StateLeader": 0,
+               "StateFollower": 0}
+STATUS = {"APPLIED": 0, "OTHER_TYPE": 1, "NO_PROGRESS": 2, "STALE_TERM": 3, "HIGHER_TERM": 4, "VOTE": 9}
+VOTE_RESULT = {"VotePending": 1, "VoteLost": 2, "VoteWon": 3}
+
+
+def replay_vote_sequence(seq, drv):
+    """One of tests/golden/scenarios.json's wire_vote_sequences through a driver with
+    become(resp_type, term) / record([(id, granted)]) / wire(bytes) -> status / tally() -> (res, gr, rj)."""
+    for k, st in enumerate(seq["steps"]):
+        where = (seq["src"], k)
+        if "become" in st:
+            drv.become(CAMPAIGN_OF[st["become"]], st["term"])  # every role change resets the votes (raft.go:774-784)
+            term = st["term"]
+            if "record" in st:
+                drv.record([(i, bool(v)) for i, v in st["record"]])
+        else:
+            m = st["msg"]
+            blob = encode_message(type=MSG_TYPES[m["type"]], to=seq["self"], frm=m["from"], term=m["term"], reject=m["reject"])
+            assert drv.wire(blob) == STATUS[st["status"]], where
+        if "result" in st:
+            assert drv.tally() == (VOTE_RESULT[st["result"]], st["granted"], st["rejected"]), where
+
+
+def random_vote_batch(rng, n, G, ids, term):
+    """n serialized responses for random groups: vote and pre-vote responses (granted / rejected; at the group's
+    term, one above, one below; from peers with and without a row), a few MsgAppResp between them."""
+    S = ids.shape[0]
+    groups = rng.integers(0, G, size=n).astype(np.uint32)
+    out = []
+    for i in range(n):
+        g = int(groups[i])
+        typ = int(rng.choice([MSG_VOTE_RESP, MSG_PRE_VOTE_RESP, MSG_APP_RESP], p=[0.45, 0.45, 0.1]))
+        frm = int(ids[rng.integers(0, S), g]) if rng.random() < 0.95 else int(rng.integers(1, 1 << 20))
+        t = int(term[g]) + int(rng.choice([-1, 0, 1], p=[0.1, 0.6, 0.3]))
+        out.append(encode_message(type=typ, to=1, frm=frm, term=max(t, 0), reject=bool(rng.random() < 0.4),
+                                  index=int(rng.integers(0, 1 << 30))))
+    return out, groups
