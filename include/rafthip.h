@@ -469,6 +469,24 @@ int rafthip_commit_changed(rafthip_engine *e, rafthip_commit_pair *dst, uint64_t
 int rafthip_commit_advance(rafthip_engine *e, rafthip_commit_pair *dst, uint64_t max_pairs,
                            uint64_t *n_advanced);
 int rafthip_read_commit(rafthip_engine *e, uint64_t first, uint64_t count, uint64_t *dst);
+/* bcastHeartbeat as serialized bytes — raft.go:698-716 (bcastHeartbeat,
+ * bcastHeartbeatWithCtx), sendHeartbeat raft.go:669-685, r.send raft.go:502-533:
+ * for every Progress row (slot s, group first+g) whose id is not 0, except the
+ * leader's own (rafthip_upload_self), the message
+ *   raftpb.Message{Type: MsgHeartbeat, To: id, From: the id of the self slot,
+ *                  Term: r.Term, Commit: min(Match, raftLog.committed),
+ *                  Context: the pending ReadIndex context, nil when none}
+ * exactly as Message.Marshal writes it (raftpb/raft.pb.go:937-1025), at
+ * out_bytes[(s*count + g) * RAFTHIP_HEARTBEAT_STRIDE], zero-padded, its length
+ * in out_len[s*count + g] (0 = no message: empty slot, own slot, or a group
+ * whose self mask is empty, i.e. not led here).  Both outputs host or device
+ * memory (device: out_bytes 8-byte aligned).  The commit plane must hold
+ * raftLog.committed (rafthip_commit_advance / rafthip_upload_commit); requires
+ * rafthip_upload_ids, _term, _self (and _read_ctx when reads are pending). */
+#define RAFTHIP_HEARTBEAT_STRIDE 72
+int rafthip_emit_heartbeats(rafthip_engine *e, uint64_t first, uint64_t count, uint8_t *out_bytes,
+                            uint8_t *out_len);
+
 
 /* raft.committedEntryInCurrentTerm for every group — raft.go:2001-2005: has the
  * leader committed an entry of its own term (raftLog.committed inside

@@ -161,3 +161,10 @@ func (b *BatchEngine) HeartbeatCommit(dst []uint64) error {
 	return hipErr(C.rafthip_heartbeat_commit(b.e, 0, C.uint64_t(b.groups), (*C.uint64_t)(unsafe.Pointer(&dst[0])),
 		C.uint64_t(b.groups)))
 }
+
+// Heartbeats: bcastHeartbeat as wire bytes (raft.go:698-716, Message.Marshal): the MsgHeartbeat to
+// slot s of group g is bytes[(s*groups+g)*72:][:lens[s*groups+g]]; length 0 = none to send.
+func (b *BatchEngine) Heartbeats(bytes, lens []uint8) error {
+	return hipErr(C.rafthip_emit_heartbeats(b.e, 0, C.uint64_t(b.groups), (*C.uint8_t)(unsafe.Pointer(&bytes[0])),
+		(*C.uint8_t)(unsafe.Pointer(&lens[0]))))
+}

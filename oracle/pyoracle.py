@@ -412,6 +412,39 @@ def decode_wire_msgs(ids, term, read_ctx, read_ctx_len, data, offsets, groups, c
     return out_msgs, aux, status, counts
 
 
+def message_marshal(type=0, to=0, frm=0, term=0, logTerm=0, index=0, commit=0, reject=False, rejectHint=0,
+                    context=None, vote=0):
+    """Message.Marshal for a message without entries / snapshot / responses -> bytes."""
+    f = lib().oracle_message_marshal
+    f.restype = C.c_int64
+    f.argtypes = [C.c_int32] + [C.c_uint64] * 6 + [C.c_int, C.c_uint64, C.c_char_p, C.c_uint64, C.c_uint64, C.c_void_p,
+                                                  C.c_uint64]
+    out = np.zeros(256 + (len(context) if context else 0), dtype=np.uint8)
+    n = f(type, to, frm, term, logTerm, index, commit, int(reject), rejectHint, context,
+          len(context) if context is not None else 0, vote, _vp(out), len(out))
+    assert n > 0, n
+    return out[:n].tobytes()
+
+
+def bcast_heartbeat(match, committed, ids, term, read_ctx, read_ctx_len, self_mask, msg_stride=72):
+    """bcastHeartbeat for every group -> (uint8 [S][G][msg_stride] zero-padded messages, uint8 [S][G] lengths)."""
+    match = _chk(match, np.uint64)
+    ids = _chk(ids, np.uint64)
+    S, G = match.shape
+    assert ids.shape == (S, G)
+    out = np.zeros((S, G, msg_stride), dtype=np.uint8)
+    lens = np.zeros((S, G), dtype=np.uint8)
+    f = lib().oracle_bcast_heartbeat
+    f.restype = None
+    f.argtypes = [C.c_uint64, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
+                  C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p]
+    self_mask = _chk(self_mask)
+    f(G, S, _vp(match), match.strides[0] // 8, _vp(_chk(committed, np.uint64)), _vp(ids), ids.strides[0] // 8,
+      _vp(_chk(term, np.uint64)), _vp(_chk(read_ctx, np.uint64)), _vp(_chk(read_ctx_len, np.uint8)), _vp(self_mask),
+      self_mask.dtype.itemsize, _vp(out), msg_stride, _vp(lens))
+    return out, lens
+
+
 def batch_check_quorum(active, nslots, self_mask, in_mask=None, out_mask=None, learner_mask=None,
                        uniform_voters=0):
     """MsgCheckQuorum for every group: returns QuorumActive u8; mutates active (all but self cleared)."""

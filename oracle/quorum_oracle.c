@@ -1007,6 +1007,122 @@ ORACLE_API void oracle_decode_wire_msgs(uint64_t G, int nslots, const uint64_t *
               offsets, groups, n, out_msgs, out_aux, out_status, counts, campaign, votes, votes_stride);
 }
 
+/* raftpb/raft.pb.go:1416-1418 — sovRaft: bytes of a varint. */
+static int pb_sov(uint64_t x) {
+    int n = 1;
+    while (x >= 0x80) {
+        x >>= 7;
+        n++;
+    }
+    return n;
+}
+
+/* raftpb/raft.pb.go:1233-1243 — encodeVarintRaft: writes v so that it ends before `offset`. */
+static int64_t pb_encode_varint(uint8_t *d, int64_t offset, uint64_t v) {
+    offset -= pb_sov(v);
+    int64_t base = offset;
+    while (v >= 0x80) {
+        d[offset++] = (uint8_t)((v & 0x7f) | 0x80);
+        v >>= 7;
+    }
+    d[offset] = (uint8_t)v;
+    return base;
+}
+
+/*
+ * raftpb/raft.pb.go:1288-1325 (Size) and :937-1025 (MarshalToSizedBuffer), for a
+ * Message without Entries, Snapshot and Responses: the buffer is filled from
+ * its end, field 13 first.  ctx == NULL is a nil Context (field 12 omitted); a
+ * non-nil empty one is written with length 0.  Returns the length, or -1 when
+ * cap is too small.
+ */
+ORACLE_API int64_t oracle_message_marshal(int32_t type, uint64_t to, uint64_t from, uint64_t term,
+                                          uint64_t log_term, uint64_t index, uint64_t commit, int reject,
+                                          uint64_t reject_hint, const uint8_t *ctx, uint64_t ctx_len,
+                                          uint64_t vote, uint8_t *out, uint64_t cap) {
+    int64_t n = 0;
+    n += 1 + pb_sov((uint64_t)(int64_t)type); /* uint64(m.Type): an int32 sign-extends */
+    n += 1 + pb_sov(to);
+    n += 1 + pb_sov(from);
+    n += 1 + pb_sov(term);
+    n += 1 + pb_sov(log_term);
+    n += 1 + pb_sov(index);
+    n += 1 + pb_sov(commit);
+    n += 2;
+    n += 1 + pb_sov(reject_hint);
+    if (ctx != NULL) n += 1 + (int64_t)ctx_len + pb_sov(ctx_len);
+    n += 1 + pb_sov(vote);
+    if ((uint64_t)n > cap) return -1;
+    uint8_t *d = out;
+    int64_t i = n;
+    i = pb_encode_varint(d, i, vote);
+    d[--i] = 0x68;
+    if (ctx != NULL) {
+        i -= (int64_t)ctx_len;
+        memcpy(d + i, ctx, ctx_len);
+        i = pb_encode_varint(d, i, ctx_len);
+        d[--i] = 0x62;
+    }
+    i = pb_encode_varint(d, i, reject_hint);
+    d[--i] = 0x58;
+    d[--i] = reject ? 1 : 0;
+    d[--i] = 0x50;
+    i = pb_encode_varint(d, i, commit);
+    d[--i] = 0x40;
+    i = pb_encode_varint(d, i, index);
+    d[--i] = 0x30;
+    i = pb_encode_varint(d, i, log_term);
+    d[--i] = 0x28;
+    i = pb_encode_varint(d, i, term);
+    d[--i] = 0x20;
+    i = pb_encode_varint(d, i, from);
+    d[--i] = 0x18;
+    i = pb_encode_varint(d, i, to);
+    d[--i] = 0x10;
+    i = pb_encode_varint(d, i, (uint64_t)(int64_t)type);
+    d[--i] = 0x8;
+    return i == 0 ? n : -2;
+}
+
+/*
+ * raft.go:698-716 — bcastHeartbeat over G groups, one leader each: Visit every
+ * Progress id but r.id, sendHeartbeat (raft.go:669-685): Commit = min(Match,
+ * committed), Context = the last pending ReadIndex context or nil; r.send fills
+ * From = r.id and Term = r.Term (raft.go:502-533).  The message of (slot s,
+ * group g) is marshalled at out[(s*G + g) * msg_stride] (zero-padded), its
+ * length in out_len[s*G + g]; 0 = none (empty slot, own slot, or no self bit:
+ * the group is not led here).
+ */
+ORACLE_API void oracle_bcast_heartbeat(uint64_t G, int nslots, const uint64_t *match, uint64_t stride,
+                                       const uint64_t *committed, const uint64_t *ids, uint64_t ids_stride,
+                                       const uint64_t *term, const uint64_t *read_ctx,
+                                       const uint8_t *read_ctx_len, const void *self_mask, int mask_bytes,
+                                       uint8_t *out, uint64_t msg_stride, uint8_t *out_len) {
+    memset(out, 0, (size_t)nslots * G * msg_stride);
+    memset(out_len, 0, (size_t)nslots * G);
+    for (uint64_t g = 0; g < G; g++) {
+        uint64_t self = load_mask(self_mask, mask_bytes, g);
+        if (self == 0) continue;
+        int me = 0;
+        while (!((self >> me) & 1)) me++;
+        if (me >= nslots) continue;
+        uint64_t my_id = ids[(uint64_t)me * ids_stride + g];
+        if (my_id == 0) continue;
+        uint8_t ctx[8];
+        for (int b = 0; b < 8; b++) ctx[b] = (uint8_t)(read_ctx[g] >> (8 * b));
+        for (int s = 0; s < nslots; s++) {
+            uint64_t id = ids[(uint64_t)s * ids_stride + g];
+            if (s == me || id == 0) continue;
+            uint64_t m = match[(uint64_t)s * stride + g];
+            uint64_t commit = m < committed[g] ? m : committed[g];
+            int64_t len = oracle_message_marshal(8 /* MsgHeartbeat */, id, my_id, term[g], 0, 0, commit, 0, 0,
+                                                 read_ctx_len[g] ? ctx : NULL, read_ctx_len[g], 0,
+                                                 out + ((uint64_t)s * G + g) * msg_stride, msg_stride);
+            out_len[(uint64_t)s * G + g] = (uint8_t)(len > 0 ? len : 0);
+        }
+    }
+}
+
 /*
  * raft.go:1231-1243 — MsgCheckQuorum over G groups: out = QuorumActive(), then
  * every Progress except the leader's own (self bit) gets RecentActive = false.

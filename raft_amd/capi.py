@@ -44,6 +44,7 @@ SYMBOLS = [
     "rafthip_read_inflights", "rafthip_upload_first_index", "rafthip_step_progress", "rafthip_step_wire",
     "rafthip_merge_acks", "rafthip_host_alloc", "rafthip_host_free",
     "rafthip_record_votes", "rafthip_read_votes", "rafthip_step_dense", "rafthip_upload_campaign",
+    "rafthip_emit_heartbeats",
 ]
 MSG_VOTE_RESP, MSG_PRE_VOTE_RESP = 6, 18
 
@@ -57,6 +58,7 @@ WIRE_STATUSES = 10
 (WIRE_APPLIED, WIRE_OTHER_TYPE, WIRE_NO_PROGRESS, WIRE_STALE_TERM, WIRE_HIGHER_TERM, WIRE_NESTED, WIRE_MALFORMED,
  WIRE_BAD_GROUP, WIRE_NEEDS_LOG, WIRE_VOTE) = range(10)
 MSG_NEEDS_HOST = 0xFE
+HEARTBEAT_STRIDE = 72
 MSGF_READ_CTX, MSGF_HAS_CTX = 1, 2
 
 
@@ -160,6 +162,7 @@ def load_library():
         "rafthip_upload_term": (i32, [vp, u64, u64, vp]),
         "rafthip_upload_read_ctx": (i32, [vp, u64, u64, vp, vp]),
         "rafthip_upload_campaign": (i32, [vp, u64, u64, vp]),
+        "rafthip_emit_heartbeats": (i32, [vp, u64, u64, vp, vp]),
         "rafthip_ingest_wire": (i32, [vp, vp, vp, vp, u64, vp, vp, vp]),
         "rafthip_progress_config": (i32, [vp, u32, u64]),
         "rafthip_upload_progress": (i32, [vp, u64, u64, vp, vp, vp, u64]),
@@ -482,6 +485,14 @@ class Engine:
         out = np.empty((self.S, count), dtype=np.uint64) if download else None
         _check(self._L.rafthip_heartbeat_commit(self._h, first, count, _ptr(out), count))
         return out
+
+    def emit_heartbeats(self, first=0, count=None):
+        """bcastHeartbeat as bytes -> (uint8 [S][count][HEARTBEAT_STRIDE] zero-padded messages, uint8 [S][count] lengths)."""
+        first, count = self._range(first, count)
+        out = np.empty((self.S, count, HEARTBEAT_STRIDE), dtype=np.uint8)
+        lens = np.empty((self.S, count), dtype=np.uint8)
+        _check(self._L.rafthip_emit_heartbeats(self._h, first, count, _ptr(out), _ptr(lens)))
+        return out, lens
 
     def committed_in_term(self, first=0, count=None):
         """raft.committedEntryInCurrentTerm for every group -> u8."""

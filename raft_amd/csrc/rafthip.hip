@@ -1626,6 +1626,60 @@ int rafthip_heartbeat_commit(rafthip_engine* e, uint64_t first, uint64_t count, 
     return RAFTHIP_OK;
 }
 
+static_assert(kHeartbeatStride == RAFTHIP_HEARTBEAT_STRIDE, "heartbeat stride");
+
+int rafthip_emit_heartbeats(rafthip_engine* e, uint64_t first, uint64_t count, uint8_t* out_bytes, uint8_t* out_len) {
+    int rc = check_range(e, first, count);
+    if (rc) return rc;
+    if (!out_bytes || !out_len) return fail(RAFTHIP_EINVAL, "out_bytes/out_len is NULL");
+    if (!e->have_ids || !e->have_term)
+        return fail(RAFTHIP_EINVAL, "rafthip_upload_ids and rafthip_upload_term must come first");
+    if (count == 0) return RAFTHIP_OK;
+    DeviceGuard guard(e->device);
+    if ((rc = ensure(e, e->self_mask, (size_t)e->stride * e->mbytes))) return rc;
+    const size_t cells = (size_t)e->S * count;
+    const bool bytes_host = !is_device_ptr(out_bytes), len_host = !is_device_ptr(out_len);
+    uint8_t *d_bytes = out_bytes, *d_len = out_len;
+    if (bytes_host) {
+        if ((rc = stage_reserve(e, 0, cells * kHeartbeatStride))) return rc;
+        d_bytes = static_cast<uint8_t*>(e->stage_buf[0]);
+    } else if (reinterpret_cast<uintptr_t>(out_bytes) % 8 != 0) {
+        return fail(RAFTHIP_EINVAL, "out_bytes on the device must be 8-byte aligned");
+    }
+    if (len_host) {
+        if ((rc = stage_reserve(e, 4, cells))) return rc;
+        d_len = static_cast<uint8_t*>(e->stage_buf[4]);
+    }
+    const u32 blocks = (u32)((count + kBlock - 1) / kBlock);
+    const u32 H = wire_hdr_words(e->S);
+#define RAFTHIP_EMIT(MT)                                                                                        \
+    hipLaunchKernelGGL((k_emit_heartbeats<MT>), dim3(blocks), dim3(kBlock), 0, e->stream, e->match, e->stride,   \
+                       e->commit, static_cast<const u64*>(e->wire_hdr), H, static_cast<const MT*>(e->self_mask), \
+                       (u64)first, (u64)count, e->S, d_bytes, d_len)
+    if (e->mbytes == 1) {
+        RAFTHIP_EMIT(uint8_t);
+    } else if (e->mbytes == 2) {
+        RAFTHIP_EMIT(uint16_t);
+    } else if (e->mbytes == 4) {
+        RAFTHIP_EMIT(uint32_t);
+    } else {
+        RAFTHIP_EMIT(uint64_t);
+    }
+#undef RAFTHIP_EMIT
+    HIP_TRY(hipGetLastError());
+    e->stats.groups_evaluated += count;
+    if (bytes_host) {
+        HIP_TRY(hipMemcpyAsync(out_bytes, d_bytes, cells * kHeartbeatStride, hipMemcpyDeviceToHost, e->stream));
+        e->stats.bytes_downloaded += cells * kHeartbeatStride;
+    }
+    if (len_host) {
+        HIP_TRY(hipMemcpyAsync(out_len, d_len, cells, hipMemcpyDeviceToHost, e->stream));
+        e->stats.bytes_downloaded += cells;
+    }
+    if (bytes_host || len_host) HIP_TRY(hipStreamSynchronize(e->stream));
+    return RAFTHIP_OK;
+}
+
 int rafthip_read_commit(rafthip_engine* e, uint64_t first, uint64_t count, uint64_t* dst) {
     int rc = check_range(e, first, count);
     if (rc) return rc;

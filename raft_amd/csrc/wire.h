@@ -336,6 +336,111 @@ __global__ __launch_bounds__(kWireBlock) void k_ingest_wire(
     if (threadIdx.x < kWireStatuses && hist[threadIdx.x] != 0) atomicAdd(counters + threadIdx.x, (u64)hist[threadIdx.x]);
 }
 
+// ---------------------------------------------------------------------------
+// K10 — bcastHeartbeat as serialized bytes (raft.go:698-716 -> sendHeartbeat
+// :669-685 -> r.send :502-533): for every Progress row of a leader's group but
+// its own, the raftpb.Message
+//   {Type: MsgHeartbeat, To: id, From: r.id, Term: r.Term,
+//    Commit: min(pr.Match, raftLog.committed), Context: the last pending
+//    ReadIndex context or nil}
+// as Message.Marshal writes it (raftpb/raft.pb.go:937-1025: every non-nullable
+// scalar in field order, Context only when non-nil).  Lane = group, loop over
+// slots; a workgroup builds its 256 messages of one slot in LDS (8-byte words,
+// zero-padded to the fixed stride) and writes them out as one contiguous run.
+// A group whose self mask is empty (not led here) emits nothing.
+// ---------------------------------------------------------------------------
+constexpr u32 kHeartbeatStride = 72;  // longest: 2+11+11+11+2+2+11+2+2+(2+8)+2 = 66 bytes
+constexpr u32 kMsgHeartbeat = 8;
+
+struct WordSink {  // appends bytes to 8-byte words in LDS
+    u64* dst;
+    u64 acc;
+    u32 nb, words;
+    __device__ __forceinline__ void put(u32 b) {
+        acc |= (u64)(b & 0xFFu) << (8 * nb);
+        if (++nb == 8) {
+            dst[words++] = acc;
+            acc = 0;
+            nb = 0;
+        }
+    }
+    // encodeVarintRaft, raft.pb.go:1233-1243
+    __device__ __forceinline__ void varint(u64 v) {
+        while (v >= 0x80) {
+            put((u32)(v & 0x7F) | 0x80u);
+            v >>= 7;
+        }
+        put((u32)v);
+    }
+    __device__ __forceinline__ u32 finish(u32 total_words) {  // -> length in bytes; the rest of the slot reads 0
+        const u32 len = words * 8 + nb;
+        if (nb != 0) dst[words++] = acc;
+        for (; words < total_words; ++words) dst[words] = 0;
+        return len;
+    }
+};
+
+template <class MaskT>
+__global__ __launch_bounds__(kBlock) void k_emit_heartbeats(
+    const u64* __restrict__ match, u64 stride, const u64* __restrict__ commit, const u64* __restrict__ hdr, u32 H,
+    const MaskT* __restrict__ self_mask, u64 first, u64 count, u32 S, uint8_t* __restrict__ out_bytes /* [S][count][72] */,
+    uint8_t* __restrict__ out_len /* [S][count] */) {
+    constexpr u32 W = kHeartbeatStride / 8;
+    __shared__ __align__(16) u64 sm2[2][kBlock * W];  // two buffers: one barrier per slot
+    const u64 g0 = (u64)blockIdx.x * kBlock;
+    const u64 gl = g0 + threadIdx.x;  // group within the range
+    const bool live = gl < count;
+    const u64 g = first + (live ? gl : 0);
+    const u64* row = hdr + g * H;
+    u64 term = 0, ctx = 0, from = 0, com = 0;
+    u32 ctx_len = 0, self_slot = kWireNoSlot;
+    if (live) {
+        const u64 self = (u64)self_mask[g];
+        if (self != 0) {
+            self_slot = (u32)__ffsll((unsigned long long)self) - 1;
+            if (self_slot < S) from = row[kHdrIds + self_slot];
+            term = row[kHdrTerm];
+            ctx = row[kHdrCtx];
+            ctx_len = (u32)(row[kHdrCtxLen] & 0xFFu);
+            com = commit[g];
+        }
+    }
+    const u64 in_block = count - g0 < (u64)kBlock ? count - g0 : (u64)kBlock;
+    for (u32 s = 0; s < S; ++s) {
+        u64* sm = sm2[s & 1];
+        WordSink w{sm + threadIdx.x * W, 0, 0, 0};
+        u32 len = 0;
+        const u64 to = live && self_slot < S && s != self_slot ? row[kHdrIds + s] : 0;
+        if (to != 0 && from != 0) {
+            const u64 m = __builtin_nontemporal_load(match + (u64)s * stride + g);
+            w.put(0x08), w.varint(kMsgHeartbeat);
+            w.put(0x10), w.varint(to);
+            w.put(0x18), w.varint(from);
+            w.put(0x20), w.varint(term);
+            w.put(0x28), w.put(0);  // LogTerm
+            w.put(0x30), w.put(0);  // Index
+            w.put(0x40), w.varint(m < com ? m : com);  // raft.go:676
+            w.put(0x50), w.put(0);  // Reject
+            w.put(0x58), w.put(0);  // RejectHint
+            if (ctx_len != 0) {     // bcastHeartbeat passes nil when nothing is pending (raft.go:699-706)
+                w.put(0x62), w.put(ctx_len);
+                for (u32 j = 0; j < ctx_len; ++j) w.put((u32)(ctx >> (8 * j)));
+            }
+            w.put(0x68), w.put(0);  // Vote
+        }
+        len = w.finish(W);
+        if (live) out_len[(u64)s * count + gl] = (uint8_t)len;
+        __syncthreads();
+        // the block's messages of this slot are one contiguous run of in_block * 72 bytes
+        uint8_t* dst = out_bytes + ((u64)s * count + g0) * kHeartbeatStride;
+        const u32 words = (u32)in_block * W;
+        u64* d64 = reinterpret_cast<u64*>(dst);  // 72 * anything is 8-byte aligned when out_bytes is
+        for (u32 k = threadIdx.x; k < words; k += kBlock) __builtin_nontemporal_store(sm[k], d64 + k);  // written once
+        // no second barrier: the next slot fills the other buffer, and this one is not refilled before every
+        // lane has passed the next slot's barrier, i.e. finished this copy
+    }
+}
+
 // ids [S][count] planes (the layout every other upload uses) -> the rows.
 __global__ __launch_bounds__(kBlock) void k_hdr_set_ids(const u64* __restrict__ src, u64 count, u32 S, u32 H,
                                                         u64* __restrict__ hdr /* row of the first group */) {

@@ -379,3 +379,68 @@ def test_vote_wire_random_batches(oracle, S, to_progress):
         e.upload_campaign(None)
         _, status2, counts2 = e.ingest_wire(data, offsets, groups)
         assert counts2[capi.WIRE_VOTE] == 0 and np.array_equal(e.read_votes(), wv)
+
+
+@pytest.mark.parametrize("S,G", [(3, 1), (5, 1000), (9, 4099), (16, 777), (33, 300), (64, 130)])
+def test_emit_heartbeats(oracle, S, G):
+    """rafthip_emit_heartbeats = bcastHeartbeat -> Message.Marshal, byte for byte against the oracle: ids up to
+    2^64-1, empty slots, groups not led here, ReadIndex contexts of every length, a partial range, device outputs."""
+    rng = np.random.default_rng(2300 + S)
+    ids, term, ctxs, match, _, _ = make_state(rng, S, G)
+    term[rng.random(G) < 0.1] = np.uint64((1 << 64) - 1)
+    mdt = gu.mask_dtype(S)
+    self_slot = rng.integers(0, S, size=G)
+    self_mask = (np.uint64(1) << self_slot.astype(np.uint64)).astype(mdt)
+    self_mask[rng.random(G) < 0.15] = 0
+    committed = match[rng.integers(0, S, size=G), np.arange(G)]
+    cw, cl = wu.ctx_words(ctxs)
+    want, want_len = oracle.bcast_heartbeat(match, committed, ids, term, cw, cl, self_mask)
+    assert want_len.max() <= capi.HEARTBEAT_STRIDE and (G < 10 or ((want_len > 0).any() and (want_len == 0).any()))
+    with raft_amd.Engine(G, S) as e:
+        e.upload_match(match)
+        e.upload_commit(committed)
+        e.upload_ids(ids)
+        e.upload_term(term)
+        e.upload_read_ctx(cw, cl)
+        e.upload_self(self_mask)
+        got, got_len = e.emit_heartbeats()
+        assert np.array_equal(got_len, want_len)
+        assert np.array_equal(got, want)
+        if G > 10:
+            a, n = G // 3, G // 2
+            got, got_len = e.emit_heartbeats(first=a, count=n)
+            assert np.array_equal(got_len, want_len[:, a:a + n]) and np.array_equal(got, want[:, a:a + n])
+            import torch
+            db = torch.full((S, G, capi.HEARTBEAT_STRIDE), 0xEE, dtype=torch.uint8, device="cuda")
+            dl = torch.full((S, G), 0xEE, dtype=torch.uint8, device="cuda")
+            L = raft_amd.load_library()
+            assert L.rafthip_emit_heartbeats(e._h, 0, G, db.data_ptr(), dl.data_ptr()) == 0
+            e.synchronize()
+            assert np.array_equal(db.cpu().numpy(), want) and np.array_equal(dl.cpu().numpy(), want_len)
+
+
+def test_emit_heartbeats_on_the_reference_cases():
+    """The heartbeats the reference's tests show (heartbeat_commit_cases), emitted by the engine and parsed by the
+    protobuf runtime: `1->2 MsgHeartbeat Term:1 Log:0/0 Commit:17` and friends."""
+    import json
+    import os
+    with open(os.path.join(gu.HERE, "golden", "scenarios.json")) as fh:
+        cases = json.load(fh)["heartbeat_commit_cases"]
+    Msg = wu.pb_message_class()
+    for c in cases:
+        n = len(c["ids"])
+        me = c["ids"].index(c["leader"])
+        with raft_amd.Engine(1, n) as e:
+            e.upload_match(np.array(c["match"], dtype=np.uint64).reshape(n, 1))
+            e.upload_commit(np.array([c["committed"]], dtype=np.uint64))
+            e.upload_ids(np.array(c["ids"], dtype=np.uint64).reshape(n, 1))
+            e.upload_term(np.array([c["term"]], dtype=np.uint64))
+            e.upload_self(np.array([1 << me], dtype=np.uint8))
+            out, lens = e.emit_heartbeats()
+            assert lens[me, 0] == 0
+            for peer, want in c["want"].items():
+                s = c["ids"].index(int(peer))
+                m = Msg()
+                m.ParseFromString(out[s, 0, :lens[s, 0]].tobytes())
+                assert (m.type, m.to, getattr(m, "from"), m.term, m.commit) == (8, int(peer), c["leader"], c["term"], want), c["src"]
+                assert not m.HasField("context")

@@ -294,3 +294,58 @@ def test_vote_wire_gates(oracle):
     _, status, _ = oracle.step_wire_msgs(drv.match, drv.bits[0], drv.bits[1], drv.ids, drv.term, z, np.zeros(1, dtype=np.uint8),
                                          data, offsets, np.zeros(1, dtype=np.uint32))
     assert status[0] == 1
+
+
+def test_message_marshal_matches_the_published_format(oracle):
+    """oracle.message_marshal (Message.Size + MarshalToSizedBuffer, raftpb/raft.pb.go:937-1025,1288-1325) against
+    the protobuf runtime's parser, the tests' own forward encoder, and Unmarshal."""
+    from oracle import pyoracle as po
+    rng = np.random.default_rng(77)
+    Msg = wu.pb_message_class()
+    for k in range(400):
+        big = lambda: int(rng.integers(0, 1 << 64, dtype=np.uint64) >> np.uint64(rng.integers(0, 64)))
+        kw = dict(type=int(rng.integers(0, 24)), to=big(), frm=big(), term=big(), logTerm=big(), index=big(), commit=big(),
+                  reject=bool(rng.random() < 0.5), rejectHint=big(), vote=big())
+        ctx = None if k % 3 == 0 else bytes(rng.integers(0, 256, size=int(rng.integers(0, 12)), dtype=np.uint8))
+        b = po.message_marshal(context=ctx, **kw)
+        assert b == wu.encode_message(context=ctx, **kw)
+        m = Msg()
+        m.ParseFromString(b)
+        assert (m.type, m.to, getattr(m, "from"), m.term, m.logTerm, m.index, m.commit, m.reject, m.rejectHint, m.vote) == (
+            kw["type"], kw["to"], kw["frm"], kw["term"], kw["logTerm"], kw["index"], kw["commit"], kw["reject"],
+            kw["rejectHint"], kw["vote"])
+        assert m.HasField("context") == (ctx is not None) and m.context == (ctx or b"")
+        rc, f = oracle.message_unmarshal(b)
+        assert rc == 0 and f["from"] == kw["frm"] and f["commit"] == kw["commit"] and f["context"] == ctx
+    # an int32 type below zero is written sign-extended: ten bytes
+    assert po.message_marshal(type=-1)[:11] == b"\x08" + b"\xff" * 9 + b"\x01"
+
+
+def test_bcast_heartbeat_on_the_reference_cases(oracle):
+    """The heartbeats the reference's tests show (tests/golden/scenarios.json heartbeat_commit_cases: From, To,
+    Term and Commit of `1->2 MsgHeartbeat Term:1 Log:0/0 Commit:17` etc.), marshalled by oracle.bcast_heartbeat
+    and parsed back by the protobuf runtime."""
+    import json
+    import os
+    with open(os.path.join(gu.HERE, "golden", "scenarios.json")) as fh:
+        cases = json.load(fh)["heartbeat_commit_cases"]
+    Msg = wu.pb_message_class()
+    for c in cases:
+        n = len(c["ids"])
+        ids = np.array(c["ids"], dtype=np.uint64).reshape(n, 1)
+        me = c["ids"].index(c["leader"])
+        for ctx in (b"", b"ctx-7"):
+            cw, cl = wu.ctx_words([ctx])
+            out, lens = oracle.bcast_heartbeat(np.array(c["match"], dtype=np.uint64).reshape(n, 1),
+                                               np.array([c["committed"]], dtype=np.uint64), ids,
+                                               np.array([c["term"]], dtype=np.uint64), cw, cl,
+                                               np.array([1 << me], dtype=np.uint8))
+            assert lens[me, 0] == 0 and not out[me].any()
+            for peer, want in c["want"].items():
+                s = c["ids"].index(int(peer))
+                m = Msg()
+                m.ParseFromString(out[s, 0, :lens[s, 0]].tobytes())
+                assert (m.type, m.to, getattr(m, "from"), m.term, m.commit) == (8, int(peer), c["leader"], c["term"], want), c["src"]
+                assert (m.logTerm, m.index, m.reject, m.rejectHint, m.vote, len(m.entries)) == (0, 0, False, 0, 0, 0)
+                assert m.HasField("context") == bool(ctx) and m.context == ctx
+                assert not out[s, 0, lens[s, 0]:].any()

@@ -284,6 +284,26 @@ def main():
             timed("k_merge_acks, dense plane, %.0f %% of cells acked (K5d)" % (100.0 * np.count_nonzero(plane) / plane.size),
                   "cell", Sv * G, 24, lambda: e.merge_acks(d_plane), setup=lambda: e.upload_match(low), iters=5)
         del plane, d_plane
+    # bcastHeartbeat as serialized bytes (K10): cfg5 shape, every group led here, ids 1..9, 8-byte ReadIndex context on half
+    if not args.only or args.only in "k_emit_heartbeats (K10)":
+        ids = np.tile(np.arange(1, Sv + 1, dtype=np.uint64)[:, None], (1, G))
+        d_out = torch.empty((Sv, G, 72), dtype=torch.uint8, device=dev)
+        d_len = torch.empty((Sv, G), dtype=torch.uint8, device=dev)
+        L = raft_amd.load_library()
+        with raft_amd.Engine(G, Sv, stream=stream.cuda_stream) as e:
+            e.set_uniform_config(7)
+            e.upload_match(m)
+            e.upload_commit(m[0])
+            e.upload_ids(ids)
+            e.upload_term(np.full(G, 7, dtype=np.uint64))
+            e.upload_read_ctx(rng.integers(0, 1 << 63, size=G).astype(np.uint64),
+                              np.where(rng.random(G) < 0.5, 8, 0).astype(np.uint8))
+            e.upload_self(np.ones(G, dtype=np.uint16))
+            # per Progress row: Match 8 + the 72-byte message slot + its length byte; the group's row, commit and
+            # self mask ((3+9 -> 12 words) * 8 + 8 + 2) are shared by its 9 rows
+            timed("k_emit_heartbeats, 8 messages per group (K10)", "row", Sv * G, 93,
+                  lambda: L.rafthip_emit_heartbeats(e._h, 0, G, d_out.data_ptr(), d_len.data_ptr()))
+        del ids, d_out, d_len
     # sorted-by-group stream (a host that buckets acks by range)
     order = np.argsort(recs["group"], kind="stable")
     d_recs = torch.from_numpy(np.ascontiguousarray(recs[order]).view(np.uint8)).to(dev)
