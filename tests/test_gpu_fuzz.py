@@ -8,6 +8,7 @@ import pytest
 import golden_util as gu
 import progress_util as pu
 import raft_amd
+import wire_util as wu
 from oracle import pyoracle as po
 from test_gpu_parity import rand_masks, rand_match
 
@@ -52,6 +53,9 @@ def test_random_call_sequences(oracle, S, G, seed):
     pl["match"] = sh["match"]
     first_index = np.zeros(G, np.uint64)
     PKEYS = ("pstate", "next", "pending", "infl_meta", "infl_bytes", "ring_index", "ring_bytes")
+    # the lookup state of the wire path: ids behind the rows, r.Term, pending ReadIndex context, campaign type
+    wire = dict(ids=np.zeros((S, G), np.uint64), term=np.zeros(G, np.uint64), cw=np.zeros(G, np.uint64),
+                cl=np.zeros(G, np.uint8), camp=np.zeros(G, np.uint8))
 
     with raft_amd.Engine(G, S) as e:
         e.upload_active(sh["active"])
@@ -60,8 +64,12 @@ def test_random_call_sequences(oracle, S, G, seed):
         e.upload_term_range(sh["tf"], sh["tl"])
         e.reset_votes()
         e.progress_config(cap, max_bytes)
-        for step in range(150):
-            op = int(rng.integers(0, 22))
+        e.upload_ids(wire["ids"])
+        e.upload_term(wire["term"])
+        e.upload_read_ctx(wire["cw"], wire["cl"])
+        e.upload_campaign(wire["camp"])
+        for step in range(170):
+            op = int(rng.integers(0, 25))
             checked[0] += 10 <= op < 16
             a, n = rng_range()
             if op == 0:
@@ -154,6 +162,45 @@ def test_random_call_sequences(oracle, S, G, seed):
                     assert np.array_equal(got[key], pl[key]), (step, key)
                 assert np.array_equal(e.read_match(), sh["match"]), step
                 assert np.array_equal(e.read_active(), sh["active"]), step
+            elif op == 22:
+                which = int(rng.integers(0, 4))
+                if which == 0:
+                    part = np.ascontiguousarray(wu.random_ids(rng, S, max(n, 1), empty_frac=0.1)[:, :n] % np.uint64(1 << 40))
+                    e.upload_ids(part, first=a, count=n)
+                    wire["ids"][:, a:a + n] = part
+                elif which == 1:
+                    part = rng.integers(0, 4, size=n).astype(np.uint64)
+                    e.upload_term(part, first=a, count=n)
+                    wire["term"][a:a + n] = part
+                elif which == 2:
+                    cl = rng.integers(0, 9, size=n).astype(np.uint8)
+                    cw = np.where(cl > 0, rng.integers(0, 4, size=n), 0).astype(np.uint64)  # fits any length >= 1
+                    e.upload_read_ctx(cw, cl, first=a, count=n)
+                    wire["cw"][a:a + n], wire["cl"][a:a + n] = cw, cl
+                else:
+                    part = rng.choice(np.array([0, 6, 18], dtype=np.uint8), size=n)
+                    e.upload_campaign(part, first=a, count=n)
+                    wire["camp"][a:a + n] = part
+            elif op == 23:
+                k = int(rng.integers(0, 400))
+                ctxs = [int(wire["cw"][g]).to_bytes(8, "little")[:int(wire["cl"][g])] for g in range(G)]
+                b1, g1 = wu.random_vote_batch(rng, k // 2, G, wire["ids"], wire["term"] + np.uint64(1))
+                b2, g2 = wu.random_batch(rng, k - k // 2, G, wire["ids"], wire["term"], ctxs)
+                order = rng.permutation(k)
+                blobs = [(b1 + b2)[i] for i in order]
+                groups = np.ascontiguousarray(np.concatenate([g1, g2])[order].astype(np.uint32))
+                data, offsets = wu.pack(blobs)
+                msgs, status, counts = e.ingest_wire(data, offsets, groups)
+                wm, ws, wc = oracle.step_wire_msgs(sh["match"], sh["active"], sh["acks"], wire["ids"], wire["term"], wire["cw"],
+                                                   wire["cl"], data, offsets, groups, campaign=wire["camp"], votes=sh["votes"])
+                assert np.array_equal(status, ws) and np.array_equal(counts, wc) and np.array_equal(msgs, wm), step
+                assert np.array_equal(e.read_votes(), sh["votes"]) and np.array_equal(e.read_match(), sh["match"]), step
+                assert np.array_equal(e.read_active(), sh["active"]) and np.array_equal(e.read_acks(), sh["acks"]), step
+            elif op == 24:
+                out, lens = e.emit_heartbeats(first=a, count=n)
+                want, wlen = oracle.bcast_heartbeat(sh["match"], sh["commit"], wire["ids"], wire["term"], wire["cw"], wire["cl"],
+                                                    sh["self"])
+                assert np.array_equal(lens, wlen[:, a:a + n]) and np.array_equal(out, want[:, a:a + n]), step
             elif op == 20:
                 k = int(rng.integers(0, 500))
                 msgs = np.zeros(k, dtype=raft_amd.MSG_DTYPE)
