@@ -1,0 +1,238 @@
+/* abi_smoke.c — every entry point of include/rafthip.h called once from plain C
+ * with exactly-sized heap buffers, over a partial group range where the entry
+ * point takes one.  Built with AddressSanitizer by tools/asan_host.sh: a
+ * staging copy or download that runs past a caller's buffer aborts here.  It
+ * checks return codes and a few invariants, not parity (tests/ does that).
+ *
+ *   cc -std=c11 -Iinclude tools/abi_smoke.c -Lraft_amd/lib -lrafthip -o abi_smoke
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "rafthip.h"
+
+#define G 3001u
+#define S 9u
+#define FIRST 130u
+#define COUNT 2049u
+#define CAP 3u
+
+static int failures;
+#define OK(call)                                                                         \
+    do {                                                                                 \
+        int rc_ = (call);                                                                \
+        if (rc_ != 0) {                                                                  \
+            fprintf(stderr, "%s:%d %s -> %d (%s)\n", __FILE__, __LINE__, #call, rc_,     \
+                    rafthip_last_error());                                               \
+            failures++;                                                                  \
+        }                                                                                \
+    } while (0)
+#define FAILS(call)                                                                      \
+    do {                                                                                 \
+        if ((call) == 0) {                                                               \
+            fprintf(stderr, "%s:%d %s succeeded, want an error\n", __FILE__, __LINE__, #call); \
+            failures++;                                                                  \
+        }                                                                                \
+    } while (0)
+
+static uint64_t rng_state = 0x5EED1234ull;
+static uint64_t rnd(void) { /* splitmix64 */
+    uint64_t z = (rng_state += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+static void *buf(size_t n) { /* exactly n bytes, filled with noise */
+    unsigned char *p = malloc(n ? n : 1);
+    for (size_t i = 0; i < n; i++) p[i] = (unsigned char)rnd();
+    return p;
+}
+static size_t put_varint(uint8_t *d, uint64_t v) {
+    size_t n = 0;
+    while (v >= 0x80) d[n++] = (uint8_t)(v | 0x80), v >>= 7;
+    d[n++] = (uint8_t)v;
+    return n;
+}
+static size_t put_msg(uint8_t *d, uint32_t type, uint64_t from, uint64_t term, uint64_t index, int reject) {
+    size_t n = 0;
+    const uint64_t f[6] = {type, 1, from, term, reject ? 3 : 0, index};
+    for (int k = 0; k < 6; k++) d[n++] = (uint8_t)((k + 1) << 3), n += put_varint(d + n, f[k]);
+    d[n++] = 0x40, d[n++] = 0;
+    d[n++] = 0x50, d[n++] = (uint8_t)(reject != 0);
+    d[n++] = 0x58, n += put_varint(d + n, index ? index - 1 : 0);
+    d[n++] = 0x68, d[n++] = 0;
+    return n;
+}
+
+int main(void) {
+    int ndev = 0;
+    OK(rafthip_device_count(&ndev));
+    if (rafthip_abi_version() != RAFTHIP_ABI_VERSION || ndev < 1) {
+        fprintf(stderr, "abi %u, %d devices\n", rafthip_abi_version(), ndev);
+        return 2;
+    }
+    rafthip_config cfg = {sizeof cfg, 0, G, S, 0, NULL};
+    rafthip_engine *e = NULL;
+    OK(rafthip_create(&cfg, &e));
+    if (!e) return 2;
+    const int mb = rafthip_mask_bytes(e);
+    if (mb != 2) failures++;
+    FAILS(rafthip_upload_match(e, G - 1, 2, NULL, 2)); /* range past the end */
+    FAILS(rafthip_create(NULL, &e));
+
+    /* configuration and the planes, partial range, exactly-sized sources */
+    uint16_t *in = buf(COUNT * 2), *out = buf(COUNT * 2), *lrn = buf(COUNT * 2);
+    for (unsigned g = 0; g < COUNT; g++) in[g] &= 0x7F, out[g] = g % 3 ? 0 : (out[g] & 0xFE), lrn[g] = 0x180 & ~(in[g] | out[g]);
+    OK(rafthip_upload_config(e, FIRST, COUNT, in, out, lrn));
+    uint64_t *match = buf((size_t)S * COUNT * 8);
+    OK(rafthip_upload_match(e, FIRST, COUNT, match, COUNT));
+    OK(rafthip_read_match(e, FIRST, COUNT, match, COUNT));
+    OK(rafthip_reset_match(e, 0, FIRST));
+    uint8_t *votes = buf((size_t)S * COUNT);
+    for (size_t i = 0; i < (size_t)S * COUNT; i++) votes[i] %= 3;
+    OK(rafthip_upload_votes(e, FIRST, COUNT, votes, COUNT));
+    OK(rafthip_reset_votes(e, FIRST, 7));
+    OK(rafthip_read_votes(e, FIRST, COUNT, votes, COUNT));
+    uint16_t *bits = buf(COUNT * 2);
+    OK(rafthip_upload_active(e, FIRST, COUNT, bits));
+    OK(rafthip_upload_acks(e, FIRST, COUNT, bits));
+    for (unsigned g = 0; g < COUNT; g++) bits[g] = (uint16_t)(g % 11 ? 1u << (g % S) : 0);
+    OK(rafthip_upload_self(e, FIRST, COUNT, bits));
+    OK(rafthip_read_active(e, FIRST, COUNT, bits));
+    OK(rafthip_read_acks(e, FIRST, COUNT, bits));
+    uint64_t *tf = buf(COUNT * 8), *tl = buf(COUNT * 8), *com = buf(COUNT * 8);
+    for (unsigned g = 0; g < COUNT; g++) tf[g] = 0, tl[g] = ~0ull, com[g] >>= 1;
+    OK(rafthip_upload_term_range(e, FIRST, COUNT, tf, tl));
+    OK(rafthip_read_term_range(e, FIRST, COUNT, tf, tl));
+    OK(rafthip_upload_commit(e, FIRST, COUNT, com));
+
+    /* record streams */
+    const size_t n = 5000;
+    rafthip_ack *acks = buf(n * sizeof *acks);
+    rafthip_msg *msgs = buf(n * sizeof *msgs);
+    uint64_t *aux = buf(n * 8);
+    uint8_t *act = buf(n);
+    for (size_t i = 0; i < n; i++) {
+        acks[i].group = (uint32_t)(rnd() % (G + 3)), acks[i].slot = (uint32_t)(rnd() % (S + 1));
+        msgs[i].group = (uint32_t)(rnd() % (G + 3)), msgs[i].slot = (uint8_t)(rnd() % (S + 1));
+        const uint8_t types[8] = {4, 9, 10, 11, 0xF0, 0xF1, 0xF2, 6};
+        msgs[i].type = types[rnd() % 8], msgs[i].reject &= 1, msgs[i].flags &= 1, msgs[i].index >>= 40, aux[i] >>= 44;
+    }
+    OK(rafthip_scatter_acks(e, acks, n));
+    OK(rafthip_ingest_msgs(e, msgs, n));
+    OK(rafthip_record_votes(e, msgs, n));
+    uint64_t *plane = buf((size_t)S * COUNT * 8);
+    OK(rafthip_merge_acks(e, FIRST, COUNT, plane, COUNT));
+
+    /* per-peer replication state */
+    OK(rafthip_progress_config(e, CAP, 100));
+    FAILS(rafthip_progress_config(e, CAP + 1, 100)); /* fixed once configured */
+    uint8_t *state = buf((size_t)S * COUNT);
+    uint64_t *next = buf((size_t)S * COUNT * 8), *pend = buf((size_t)S * COUNT * 8), *ib = buf((size_t)S * COUNT * 8);
+    uint32_t *im = buf((size_t)S * COUNT * 4);
+    uint64_t *ri = buf((size_t)CAP * S * COUNT * 8), *rb = buf((size_t)CAP * S * COUNT * 8);
+    for (size_t i = 0; i < (size_t)S * COUNT; i++) state[i] = (uint8_t)((state[i] % 3) | (state[i] & 4)), im[i] = 0, ib[i] = 0;
+    OK(rafthip_upload_progress(e, FIRST, COUNT, state, next, pend, COUNT));
+    OK(rafthip_upload_inflights(e, FIRST, COUNT, im, ib, ri, rb, COUNT));
+    OK(rafthip_upload_first_index(e, FIRST, COUNT, com));
+    OK(rafthip_step_progress(e, msgs, aux, n, act));
+    OK(rafthip_step_progress(e, msgs, NULL, n, NULL));
+    uint8_t *dact = buf((size_t)S * COUNT);
+    OK(rafthip_step_dense(e, FIRST, COUNT, plane, COUNT, bits, bits, dact, COUNT));
+    OK(rafthip_read_progress(e, FIRST, COUNT, state, next, pend, im, ib, COUNT));
+    OK(rafthip_read_inflights(e, FIRST, COUNT, ri, rb, COUNT));
+
+    /* the wire path */
+    uint64_t *ids = buf((size_t)S * COUNT * 8), *term = buf(COUNT * 8), *ctx = buf(COUNT * 8);
+    uint8_t *ctx_len = buf(COUNT), *camp = buf(COUNT);
+    for (size_t i = 0; i < (size_t)S * COUNT; i++) ids[i] = 1 + i / COUNT;
+    for (unsigned g = 0; g < COUNT; g++) term[g] = 5, ctx_len[g] %= 9, camp[g] = (uint8_t)(g % 3 == 0 ? 6 : g % 3 == 1 ? 18 : 0);
+    FAILS(rafthip_ingest_wire(e, (const uint8_t *)"", (const uint64_t *)tf, (const uint32_t *)tf, 1, NULL, NULL, NULL)); /* ids first */
+    OK(rafthip_upload_ids(e, FIRST, COUNT, ids, COUNT));
+    OK(rafthip_upload_term(e, FIRST, COUNT, term));
+    OK(rafthip_upload_read_ctx(e, FIRST, COUNT, ctx, ctx_len));
+    OK(rafthip_upload_campaign(e, FIRST, COUNT, camp));
+    uint8_t *wire = malloc(n * 64);
+    uint64_t *off = buf((n + 1) * 8);
+    uint32_t *grp = buf(n * 4);
+    size_t nb = 0;
+    for (size_t i = 0; i < n; i++) {
+        const uint32_t types[4] = {4, 9, 6, 18};
+        off[i] = nb;
+        grp[i] = (uint32_t)(FIRST + rnd() % COUNT);
+        nb += put_msg(wire + nb, types[rnd() % 4], 1 + rnd() % (S + 1), 4 + rnd() % 3, rnd() >> 44, (int)(rnd() & 1));
+    }
+    off[n] = nb;
+    uint8_t *exact = malloc(nb ? nb : 1); /* the byte stream, sized to the byte */
+    memcpy(exact, wire, nb);
+    rafthip_msg *omsgs = buf(n * sizeof *omsgs);
+    uint8_t *ostat = buf(n);
+    uint64_t counts[RAFTHIP_WIRE_STATUSES], sum = 0;
+    OK(rafthip_ingest_wire(e, exact, off, grp, n, omsgs, ostat, counts));
+    for (int k = 0; k < RAFTHIP_WIRE_STATUSES; k++) sum += counts[k];
+    if (sum != n || counts[RAFTHIP_WIRE_VOTE] == 0 || counts[RAFTHIP_WIRE_APPLIED] == 0) {
+        fprintf(stderr, "wire counts: sum %llu votes %llu applied %llu\n", (unsigned long long)sum,
+                (unsigned long long)counts[RAFTHIP_WIRE_VOTE], (unsigned long long)counts[RAFTHIP_WIRE_APPLIED]);
+        failures++;
+    }
+    OK(rafthip_step_wire(e, exact, off, grp, n, omsgs, ostat, counts, act));
+    OK(rafthip_step_wire(e, exact, off, grp, n, NULL, NULL, NULL, NULL));
+    OK(rafthip_upload_campaign(e, 0, G, NULL));
+    uint8_t *hb = buf((size_t)S * COUNT * RAFTHIP_HEARTBEAT_STRIDE), *hlen = buf((size_t)S * COUNT);
+    OK(rafthip_emit_heartbeats(e, FIRST, COUNT, hb, hlen));
+    for (size_t i = 0; i < (size_t)S * COUNT; i++)
+        if (hlen[i] > RAFTHIP_HEARTBEAT_STRIDE || (hlen[i] && hb[i * RAFTHIP_HEARTBEAT_STRIDE] != 0x08)) failures++;
+
+    /* quorum arithmetic and its read-backs */
+    rafthip_commit_pair *pairs = buf(100 * sizeof *pairs); /* fewer than can change: the copy is clipped */
+    uint64_t np = 0;
+    OK(rafthip_commit(e));
+    OK(rafthip_read_commit(e, FIRST, COUNT, com));
+    OK(rafthip_commit_changed(e, pairs, 100, &np));
+    OK(rafthip_upload_commit(e, FIRST, COUNT, tf));
+    OK(rafthip_commit_advance(e, pairs, 100, &np));
+    OK(rafthip_commit_advance(e, NULL, 0, &np));
+    uint8_t *r8 = buf(COUNT), *g8 = buf(COUNT), *j8 = buf(COUNT);
+    OK(rafthip_committed_in_term(e));
+    OK(rafthip_read_committed_in_term(e, FIRST, COUNT, r8));
+    OK(rafthip_heartbeat_commit(e, FIRST, COUNT, match, COUNT));
+    OK(rafthip_tally_votes(e));
+    OK(rafthip_read_vote_result(e, FIRST, COUNT, r8, g8, j8));
+    OK(rafthip_read_vote_result(e, FIRST, COUNT, r8, NULL, NULL));
+    OK(rafthip_quorum_active(e));
+    OK(rafthip_read_quorum_active(e, FIRST, COUNT, r8));
+    OK(rafthip_check_quorum(e));
+    OK(rafthip_ack_quorum(e));
+    OK(rafthip_read_ack_quorum(e, FIRST, COUNT, r8));
+    OK(rafthip_set_uniform_config(e, 7));
+    OK(rafthip_commit(e));
+    OK(rafthip_tally_votes(e));
+    void *dev = NULL;
+    uint64_t stride = 0;
+    OK(rafthip_plane(e, 0, &dev, &stride));
+    if (!dev || stride < G) failures++;
+    rafthip_stats_t st;
+    OK(rafthip_stats(e, &st));
+    OK(rafthip_synchronize(e));
+
+    /* one-shot forms and page-locked buffers */
+    uint64_t *one = buf(COUNT * 8);
+    OK(rafthip_batch_committed_index(0, COUNT, S, match, in, out, one));
+    OK(rafthip_batch_vote_result(0, COUNT, S, votes, in, out, r8));
+    void *pin = NULL;
+    OK(rafthip_host_alloc(&pin, n * sizeof *acks));
+    if (pin) {
+        memcpy(pin, acks, n * sizeof *acks);
+        OK(rafthip_scatter_acks(e, pin, n));
+        OK(rafthip_host_free(pin));
+    }
+    OK(rafthip_destroy(e));
+    if (failures) {
+        fprintf(stderr, "abi_smoke: %d failure(s)\n", failures);
+        return 1;
+    }
+    printf("abi_smoke ok: %llu groups evaluated, %llu messages ingested\n", (unsigned long long)st.groups_evaluated,
+           (unsigned long long)st.msgs_ingested);
+    return 0;
+}
