@@ -105,3 +105,22 @@ def test_header_is_plain_c():
         open(src, "w").write('#include "rafthip.h"\nint main(void) { return (int)sizeof(rafthip_msg) - 16; }\n')
         subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I" + os.path.join(ROOT, "include"),
                                "-c", src, "-o", os.path.join(d, "t.o")])
+
+
+def test_header_is_plain_c_and_the_smoke_program_calls_every_entry_point(tmp_path):
+    """include/rafthip.h compiles as C11 with warnings on, tools/abi_smoke.c (the program the ASan pass runs on
+    the GPU box) links against the in-tree library, and it calls every declared function."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    src = os.path.join(ROOT, "tools", "abi_smoke.c")
+    out = str(tmp_path / "abi_smoke")
+    libdir = os.path.dirname(capi.library_path())
+    r = subprocess.run(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), src, "-L", libdir,
+                        "-lrafthip", "-Wl,-rpath-link,/opt/rocm/lib", "-Wl,--unresolved-symbols=ignore-in-shared-libs", "-o", out],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    text = open(src).read()
+    missing = [s for s in capi.SYMBOLS if not re.search(r"\b%s\(" % s, text)]
+    assert not missing, missing
