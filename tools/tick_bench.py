@@ -3,7 +3,7 @@
 2^22 groups x (7 voters + 2 learners), 2^24 serialized responses in ->
   rafthip_step_wire        decode + term gate + Progress lookup + Progress / Inflights stepping
   rafthip_commit_advance   quorum index + raftLog.maybeCommit's term guard, advanced pairs out
-  rafthip_heartbeat_commit min(Match, committed) per peer
+  rafthip_emit_heartbeats  bcastHeartbeat as serialized MsgHeartbeat bytes (Commit = min(Match, committed) per peer)
   rafthip_check_quorum     QuorumActive + RecentActive reset
 Per-stage and whole-tick time from HIP events on the engine's stream; a development tool,
 bench.py stays the headline."""
@@ -49,6 +49,8 @@ def main():
     d_status = torch.zeros(N, dtype=torch.uint8, device=dev)
     d_act = torch.zeros(N, dtype=torch.uint8, device=dev)
     last = pl["match"].max(axis=0) + np.uint64(128)
+    d_hbytes = torch.empty((S, G, 72), dtype=torch.uint8, device=dev)
+    d_hlen = torch.empty((S, G), dtype=torch.uint8, device=dev)
     L = raft_amd.load_library()
     with raft_amd.Engine(G, S, stream=stream.cuda_stream) as e:
         e.set_uniform_config(V)
@@ -70,7 +72,7 @@ def main():
             ("step_wire", lambda: L.rafthip_step_wire(e._h, d_data.data_ptr(), d_off.data_ptr(), d_grp.data_ptr(), N, None,
                                                      d_status.data_ptr(), None, d_act.data_ptr())),
             ("commit_advance", lambda: e.commit_advance(max_pairs=0)),
-            ("heartbeat_commit", lambda: e.heartbeat_commit(download=False)),
+            ("emit_heartbeats", lambda: L.rafthip_emit_heartbeats(e._h, 0, G, d_hbytes.data_ptr(), d_hlen.data_ptr())),
             ("check_quorum", lambda: e.check_quorum()),
         ]
         times = {k: [] for k, _ in stages}
@@ -119,6 +121,8 @@ def main():
                           "stage_ms": out, "tick_ms": round(tick, 3), "messages_per_s": N / tick * 1e3,
                           "groups_advanced": int(advanced), "applied": int((d_status == 0).sum().item()),
                           "updated": int(((d_act & 2) != 0).sum().item()),
+                          "heartbeats_out": int((d_hlen != 0).sum().item()),
+                          "heartbeat_bytes_out": int(d_hlen.sum(dtype=torch.int64).item()),
                           "dense": {"events": dense_events, "stage_ms": out_d, "tick_ms": round(sum(out_d.values()), 3),
                                     "events_per_s": dense_events / sum(out_d.values()) * 1e3}}))
 
