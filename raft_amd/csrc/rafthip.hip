@@ -59,6 +59,19 @@ int mask_bytes_for(u32 S) { return S <= 8 ? 1 : S <= 16 ? 2 : S <= 32 ? 4 : 8; }
 
 }  // namespace
 
+// Roles of the engine's staging buffers (an entry point uses each role for one thing at a time).
+enum StageSlot : int {
+    kStageBytes = 0,  // serialized message bytes in / heartbeat bytes out
+    kStageOffsets,    // message offsets / heartbeat-response masks of a dense tick
+    kStageGroups,     // envelope group ids / ReadIndex-context masks of a dense tick
+    kStageMsgs,       // decoded records
+    kStageStatus,     // per-message status / heartbeat lengths
+    kStageAux,        // aux words of events / a dense ack plane
+    kStageActions,    // action bytes
+    kStagePrev,       // per-event list links of the Progress stepper
+    kStageSlots
+};
+
 struct rafthip_engine {
     int device = 0;
     u64 G = 0;
@@ -115,9 +128,9 @@ struct rafthip_engine {
     bool have_ids = false, have_term = false;
     bool campaigning = false;  // rafthip_upload_campaign named a vote response type for some group
     u64* d_wire_counts = nullptr;  // [RAFTHIP_WIRE_STATUSES]
-    // growable staging: wire bytes, offsets, groups, out msgs, out status; progress aux, actions, prev links
-    void* stage_buf[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    size_t stage_cap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // growable device staging for host-side inputs and outputs, one buffer per role
+    void* stage_buf[kStageSlots] = {};
+    size_t stage_cap[kStageSlots] = {};
 
     // per-peer replication state (rafthip_progress_config)
     bool zero_copy_pending = false;  // a kernel on the stream reads the caller's page-locked memory: wait before returning
@@ -493,7 +506,7 @@ bool is_device_ptr(const void* p) {
 }
 
 // Growable device staging buffer k (wire bytes / offsets / groups / records / statuses, aux words, action bytes, list links).
-int stage_reserve(rafthip_engine* e, int k, size_t bytes) {
+int stage_reserve(rafthip_engine* e, StageSlot k, size_t bytes) {
     if (e->stage_cap[k] >= bytes) return RAFTHIP_OK;
     if (e->stage_buf[k]) {
         HIP_TRY(hipStreamSynchronize(e->stream));
@@ -507,7 +520,7 @@ int stage_reserve(rafthip_engine* e, int k, size_t bytes) {
 }
 
 // Input k as a device-visible pointer: device memory and page-locked host memory as they are, pageable host memory copied in.
-int stage_input(rafthip_engine* e, int k, const void* src, size_t bytes, const void** dev) {
+int stage_input(rafthip_engine* e, StageSlot k, const void* src, size_t bytes, const void** dev) {
     if (bytes == 0) {
         *dev = src;
         return RAFTHIP_OK;
@@ -633,11 +646,11 @@ int rafthip_destroy(rafthip_engine* e) {
                     e->active,  e->acks,       e->vote_result,  e->granted,  e->rejected, e->qactive,
                     e->ack_result, e->stage,   e->packed,       e->counts,   e->offsets,  e->ack_buf,
                     e->d_rejected, e->self_mask, e->term_first, e->term_last, e->hb_commit, e->in_term,
-                    e->wire_hdr, e->d_wire_counts,
-                    e->stage_buf[0], e->stage_buf[1], e->stage_buf[2], e->stage_buf[3], e->stage_buf[4],
-                    e->stage_buf[5], e->stage_buf[6], e->stage_buf[7], e->pp.rec, e->pp.ring_index, e->pp.ring_bytes,
+                    e->wire_hdr, e->d_wire_counts, e->pp.rec, e->pp.ring_index, e->pp.ring_bytes,
                     e->first_index, e->vote_first};
     for (void* b : bufs)
+        if (b) (void)hipFree(b);
+    for (void* b : e->stage_buf)
         if (b) (void)hipFree(b);
     if (e->h_scalar) (void)hipHostFree(e->h_scalar);
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
@@ -881,9 +894,9 @@ int rafthip_merge_acks(rafthip_engine* e, uint64_t first, uint64_t count, const 
     bool staged = false;
     if (!is_device_ptr(acks)) {  // host plane: staged through the engine's growable buffer, packed to pitch = count
         d_stride = (count + 1) & ~1ull;
-        if ((rc = stage_reserve(e, 5, (size_t)d_stride * e->S * sizeof(u64)))) return rc;
-        if ((rc = copy_rows(e, e->stage_buf[5], d_stride * 8, acks, src_stride * 8, count * 8, e->S))) return rc;
-        d_acks = static_cast<const u64*>(e->stage_buf[5]);
+        if ((rc = stage_reserve(e, kStageAux, (size_t)d_stride * e->S * sizeof(u64)))) return rc;
+        if ((rc = copy_rows(e, e->stage_buf[kStageAux], d_stride * 8, acks, src_stride * 8, count * 8, e->S))) return rc;
+        d_acks = static_cast<const u64*>(e->stage_buf[kStageAux]);
         e->stats.bytes_uploaded += count * 8 * e->S;
         staged = true;
     }
@@ -1125,12 +1138,12 @@ static int wire_run(rafthip_engine* e, const uint8_t* bytes, const uint64_t* off
         d_off = offsets;
     } else {
         nbytes = offsets[n];
-        if ((rc = stage_input(e, 1, offsets, (size_t)(n + 1) * sizeof(u64), &d_off))) return rc;
+        if ((rc = stage_input(e, kStageOffsets, offsets, (size_t)(n + 1) * sizeof(u64), &d_off))) return rc;
     }
     if (nbytes > 0 && !bytes) return fail(RAFTHIP_EINVAL, "bytes is NULL");
     const void *d_bytes = nullptr, *d_groups = nullptr;
-    if ((rc = stage_input(e, 0, bytes, (size_t)nbytes, &d_bytes))) return rc;
-    if ((rc = stage_input(e, 2, groups, (size_t)n * sizeof(u32), &d_groups))) return rc;
+    if ((rc = stage_input(e, kStageBytes, bytes, (size_t)nbytes, &d_bytes))) return rc;
+    if ((rc = stage_input(e, kStageGroups, groups, (size_t)n * sizeof(u32), &d_groups))) return rc;
     Msg* d_msgs = nullptr;
     uint8_t* d_status = nullptr;
     const bool msgs_host = out_msgs && !is_device_ptr(out_msgs);
@@ -1138,18 +1151,18 @@ static int wire_run(rafthip_engine* e, const uint8_t* bytes, const uint64_t* off
     if (out_msgs && !msgs_host) {
         d_msgs = reinterpret_cast<Msg*>(out_msgs);
     } else if (out_msgs || to_progress || e->campaigning) {
-        if ((rc = stage_reserve(e, 3, (size_t)n * sizeof(Msg)))) return rc;
-        d_msgs = static_cast<Msg*>(e->stage_buf[3]);
+        if ((rc = stage_reserve(e, kStageMsgs, (size_t)n * sizeof(Msg)))) return rc;
+        d_msgs = static_cast<Msg*>(e->stage_buf[kStageMsgs]);
     }
     u64* d_aux = nullptr;
     if (to_progress) {
-        if ((rc = stage_reserve(e, 5, (size_t)n * sizeof(u64)))) return rc;
-        d_aux = static_cast<u64*>(e->stage_buf[5]);
+        if ((rc = stage_reserve(e, kStageAux, (size_t)n * sizeof(u64)))) return rc;
+        d_aux = static_cast<u64*>(e->stage_buf[kStageAux]);
     }
     if (out_status) {
         if (status_host) {
-            if ((rc = stage_reserve(e, 4, (size_t)n))) return rc;
-            d_status = static_cast<uint8_t*>(e->stage_buf[4]);
+            if ((rc = stage_reserve(e, kStageStatus, (size_t)n))) return rc;
+            d_status = static_cast<uint8_t*>(e->stage_buf[kStageStatus]);
         } else {
             d_status = out_status;
         }
@@ -1159,11 +1172,11 @@ static int wire_run(rafthip_engine* e, const uint8_t* bytes, const uint64_t* off
     u32* d_prev = nullptr;
     if (to_progress) {  // the decode kernel also links each event into its Progress's list (k_progress_link's work)
         if (act_host) {
-            if ((rc = stage_reserve(e, 6, (size_t)n))) return rc;
-            d_act = static_cast<uint8_t*>(e->stage_buf[6]);
+            if ((rc = stage_reserve(e, kStageActions, (size_t)n))) return rc;
+            d_act = static_cast<uint8_t*>(e->stage_buf[kStageActions]);
         }
-        if ((rc = stage_reserve(e, 7, (size_t)n * sizeof(u32)))) return rc;
-        d_prev = static_cast<u32*>(e->stage_buf[7]);
+        if ((rc = stage_reserve(e, kStagePrev, (size_t)n * sizeof(u32)))) return rc;
+        d_prev = static_cast<u32*>(e->stage_buf[kStagePrev]);
     }
     HIP_TRY(hipMemsetAsync(e->d_wire_counts, 0, RAFTHIP_WIRE_STATUSES * sizeof(u64), e->stream));
     for (u64 off = 0; off < n; off += kMaxRecordsPerLaunch) {
@@ -1413,8 +1426,8 @@ static int progress_passes(rafthip_engine* e, const Msg* d_msgs, const u64* d_au
     const size_t mb = (size_t)e->stride * e->mbytes;
     if ((rc = ensure(e, e->active, mb))) return rc;
     if ((rc = ensure(e, e->acks, mb))) return rc;
-    if ((rc = stage_reserve(e, 7, (size_t)n * sizeof(u32)))) return rc;
-    u32* prev = static_cast<u32*>(e->stage_buf[7]);
+    if ((rc = stage_reserve(e, kStagePrev, (size_t)n * sizeof(u32)))) return rc;
+    u32* prev = static_cast<u32*>(e->stage_buf[kStagePrev]);
     const u32 blocks = (u32)((n + kBlock - 1) / kBlock);
     if (!linked) {
         hipLaunchKernelGGL(k_progress_link, dim3(blocks), dim3(kBlock), 0, e->stream, d_msgs, (u32)n, e->G, e->S,
@@ -1451,21 +1464,21 @@ int rafthip_step_dense(rafthip_engine* e, uint64_t first, uint64_t count, const 
             d_acks = acks;
         } else {
             d_ack_stride = count;
-            if ((rc = stage_reserve(e, 5, (size_t)count * e->S * sizeof(u64)))) return rc;
-            if ((rc = copy_rows(e, e->stage_buf[5], count * 8, acks, ack_stride * 8, count * 8, e->S))) return rc;
-            d_acks = e->stage_buf[5];
+            if ((rc = stage_reserve(e, kStageAux, (size_t)count * e->S * sizeof(u64)))) return rc;
+            if ((rc = copy_rows(e, e->stage_buf[kStageAux], count * 8, acks, ack_stride * 8, count * 8, e->S))) return rc;
+            d_acks = e->stage_buf[kStageAux];
             e->stats.bytes_uploaded += count * 8 * e->S;
         }
     }
-    if (hb_mask && (rc = stage_input(e, 1, hb_mask, (size_t)count * mb, &d_hb))) return rc;
-    if (hb_ctx_mask && (rc = stage_input(e, 2, hb_ctx_mask, (size_t)count * mb, &d_ctx))) return rc;
+    if (hb_mask && (rc = stage_input(e, kStageOffsets, hb_mask, (size_t)count * mb, &d_hb))) return rc;
+    if (hb_ctx_mask && (rc = stage_input(e, kStageGroups, hb_ctx_mask, (size_t)count * mb, &d_ctx))) return rc;
     const bool act_host = actions && !is_device_ptr(actions);
     uint8_t* d_act = actions;
     u64 d_act_stride = act_stride;
     if (act_host) {
         d_act_stride = count;
-        if ((rc = stage_reserve(e, 6, (size_t)count * e->S))) return rc;
-        d_act = static_cast<uint8_t*>(e->stage_buf[6]);
+        if ((rc = stage_reserve(e, kStageActions, (size_t)count * e->S))) return rc;
+        d_act = static_cast<uint8_t*>(e->stage_buf[kStageActions]);
     }
     e->pp.match = e->match;
     const u32 blocks = (u32)((count + kBlock - 1) / kBlock);
@@ -1514,12 +1527,12 @@ int rafthip_step_progress(rafthip_engine* e, const rafthip_msg* msgs, const uint
     bool staged = false;
     if ((rc = stage_records(e, msgs, n, &d_recs, &staged))) return rc;
     const void* d_aux = nullptr;
-    if (aux && (rc = stage_input(e, 5, aux, (size_t)n * sizeof(u64), &d_aux))) return rc;
+    if (aux && (rc = stage_input(e, kStageAux, aux, (size_t)n * sizeof(u64), &d_aux))) return rc;
     const bool act_host = !actions || !is_device_ptr(actions);
     uint8_t* d_act = actions;
     if (act_host) {
-        if ((rc = stage_reserve(e, 6, (size_t)n))) return rc;
-        d_act = static_cast<uint8_t*>(e->stage_buf[6]);
+        if ((rc = stage_reserve(e, kStageActions, (size_t)n))) return rc;
+        d_act = static_cast<uint8_t*>(e->stage_buf[kStageActions]);
     }
     if ((rc = progress_passes(e, static_cast<const Msg*>(d_recs), static_cast<const u64*>(d_aux), n, d_act, false)))
         return rc;
@@ -1641,14 +1654,14 @@ int rafthip_emit_heartbeats(rafthip_engine* e, uint64_t first, uint64_t count, u
     const bool bytes_host = !is_device_ptr(out_bytes), len_host = !is_device_ptr(out_len);
     uint8_t *d_bytes = out_bytes, *d_len = out_len;
     if (bytes_host) {
-        if ((rc = stage_reserve(e, 0, cells * kHeartbeatStride))) return rc;
-        d_bytes = static_cast<uint8_t*>(e->stage_buf[0]);
+        if ((rc = stage_reserve(e, kStageBytes, cells * kHeartbeatStride))) return rc;
+        d_bytes = static_cast<uint8_t*>(e->stage_buf[kStageBytes]);
     } else if (reinterpret_cast<uintptr_t>(out_bytes) % 8 != 0) {
         return fail(RAFTHIP_EINVAL, "out_bytes on the device must be 8-byte aligned");
     }
     if (len_host) {
-        if ((rc = stage_reserve(e, 4, cells))) return rc;
-        d_len = static_cast<uint8_t*>(e->stage_buf[4]);
+        if ((rc = stage_reserve(e, kStageStatus, cells))) return rc;
+        d_len = static_cast<uint8_t*>(e->stage_buf[kStageStatus]);
     }
     const u32 blocks = (u32)((count + kBlock - 1) / kBlock);
     const u32 H = wire_hdr_words(e->S);
