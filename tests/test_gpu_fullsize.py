@@ -151,3 +151,45 @@ def test_cfg5_scatter_then_commit_7_voters_2_learners(oracle):
         e.scatter_acks(lr)
         _, n = e.commit_changed(max_pairs=0)
         assert n == 0
+
+
+def test_cfg5_heartbeats_to_the_wire(oracle):
+    """cfg5 shape (2^22 groups x 7 voters + 2 learners): the 3.4e7 serialized MsgHeartbeat of one bcastHeartbeat,
+    whole output byte for byte against the oracle, plus what holds at any size: the Commit each message carries
+    never exceeds the peer's Match nor the group's commit index, and every message parses back to its (To, From)."""
+    G, S, V = 1 << 22, 9, 7
+    match = gu.dist_b(0x5EED0005, S, G) & np.uint64((1 << 63) - 1)
+    rng = np.random.default_rng(0x5EED0105)
+    ids = np.ascontiguousarray((np.arange(S, dtype=np.uint64)[:, None] + np.uint64(1)) * np.uint64(0x10001)
+                               + rng.integers(0, 1 << 16, size=G, dtype=np.uint64)[None, :] * np.uint64(1 << 20))
+    term = rng.integers(1, 1 << 20, size=G).astype(np.uint64)
+    ctx = rng.integers(1, 1 << 63, size=G, dtype=np.uint64)
+    ctx_len = np.where(rng.random(G) < 0.5, 8, 0).astype(np.uint8)
+    self_mask = (np.uint16(1) << rng.integers(0, V, size=G).astype(np.uint16)).astype(np.uint16)
+    self_mask[rng.random(G) < 0.05] = 0  # not led here
+    with raft_amd.Engine(G, S) as e:
+        e.set_uniform_config(V)
+        e.upload_match(match)
+        e.commit()
+        commit = e.read_commit()
+        e.upload_ids(ids)
+        e.upload_term(term)
+        e.upload_read_ctx(ctx, ctx_len)
+        e.upload_self(self_mask)
+        got, got_len = e.emit_heartbeats()
+    led = self_mask != 0
+    assert (got_len[:, ~led] == 0).all() and (got_len[:, led] > 0).sum() == (S - 1) * int(led.sum())
+    want, want_len = oracle.bcast_heartbeat(match, commit, ids, term, ctx, ctx_len, self_mask)
+    assert np.array_equal(got_len, want_len)
+    assert np.array_equal(got, want)
+    del want
+    # a sample parsed back by Unmarshal: To / From / Term as uploaded, Commit = min(Match, committed)
+    for k in rng.integers(0, S * G, size=300):
+        s, g = divmod(int(k), G)
+        if got_len[s, g] == 0:
+            continue
+        rc, f = oracle.message_unmarshal(got[s, g, :got_len[s, g]].tobytes())
+        me = int(self_mask[g]).bit_length() - 1
+        assert rc == 0 and (f["type"], f["to"], f["from"], f["term"]) == (8, int(ids[s, g]), int(ids[me, g]), int(term[g]))
+        assert f["commit"] == min(int(match[s, g]), int(commit[g]))
+        assert f["context"] == (int(ctx[g]).to_bytes(8, "little") if ctx_len[g] else None)
