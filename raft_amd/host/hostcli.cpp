@@ -18,6 +18,7 @@
 //   leader <g> <self> <term_first> <last_index> | follower <g> | setcommitted <g> <c>
 //   appended <g> <last_index> | step <g> <from> <type> <index> <reject 0|1> <ctx 0|1>
 //   maybecommit | checkquorum | hbcommit <g> <id>
+//   heartbeats <g> <term> [ctx-hex]  -> "heartbeat <g> <to> <hex bytes>" per peer, then "heartbeats-done <n>"
 //   progress <max_inflight> <max_bytes> | firstindex <g> <i>
 //   initprogress <g> <default_next> rows=<id>:<state>:<match>:<next>:<pending>:<paused>,...
 //   ev <g> <peer> <type> <index> <reject 0|1> <flag 0|1> <aux>     queued
@@ -29,6 +30,7 @@
 #include <string.h>
 
 #include <iostream>
+#include <map>
 #include <memory>
 #include <sstream>
 #include <string>
@@ -253,6 +255,19 @@ int main() {
                 uint64_t c = 0;
                 if (!(rc = trk->HeartbeatCommit(u(1), u(2), &c)))
                     printf("hbcommit %" PRIu64 " %" PRIu64 " %" PRIu64 "\n", u(1), u(2), c);
+            } else if (cmd == "heartbeats") {
+                std::string ctx;
+                if (t.size() > 3)
+                    for (size_t i = 0; i + 1 < t[3].size(); i += 2) ctx.push_back((char)strtoul(t[3].substr(i, 2).c_str(), nullptr, 16));
+                std::map<uint64_t, std::string> msgs;
+                if (!(rc = trk->BcastHeartbeat(u(1), u(2), ctx, &msgs))) {
+                    for (const auto& kv : msgs) {
+                        printf("heartbeat %" PRIu64 " %" PRIu64 " ", u(1), kv.first);
+                        for (unsigned char c : kv.second) printf("%02x", c);
+                        printf("\n");
+                    }
+                    printf("heartbeats-done %zu\n", msgs.size());
+                }
             } else {
                 rc = RAFTHIP_EINVAL;
                 err = "unknown command";

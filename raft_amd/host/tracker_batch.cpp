@@ -514,6 +514,32 @@ int BatchProgressTracker::HeartbeatCommit(uint64_t group, uint64_t id, uint64_t*
 
 // ---- per-peer replication state ------------------------------------------------
 
+int BatchProgressTracker::BcastHeartbeat(uint64_t group, uint64_t term, const std::string& ctx,
+                                         std::map<uint64_t, std::string>* msgs) {
+    if (!msgs) return fail(RAFTHIP_EINVAL, "msgs is NULL");
+    if (group >= G_) return fail(RAFTHIP_ERANGE, "group %llu outside [0, %llu)", (unsigned long long)group,
+                                 (unsigned long long)G_);
+    if (ctx.size() > 8) return fail(RAFTHIP_EINVAL, "a ReadIndex context of %zu bytes: the engine tracks at most 8", ctx.size());
+    int rc = Flush();
+    if (rc) return rc;
+    // the lookup state of the wire path for this group: ids behind the rows, r.Term, the pending context
+    if ((rc = lib(rafthip_upload_ids(e_, group, 1, ids_.data() + group * S_, 1)))) return rc;
+    if ((rc = lib(rafthip_upload_term(e_, group, 1, &term)))) return rc;
+    uint64_t word = 0;
+    for (size_t i = 0; i < ctx.size(); ++i) word |= (uint64_t)(uint8_t)ctx[i] << (8 * i);
+    const uint8_t len = (uint8_t)ctx.size();
+    if ((rc = lib(rafthip_upload_read_ctx(e_, group, 1, &word, &len)))) return rc;
+    if ((rc = lib(rafthip_upload_self(e_, group, 1, self_.data() + group * mb_)))) return rc;
+    std::vector<uint8_t> bytes((size_t)S_ * RAFTHIP_HEARTBEAT_STRIDE), lens(S_);
+    if ((rc = lib(rafthip_emit_heartbeats(e_, group, 1, bytes.data(), lens.data())))) return rc;
+    msgs->clear();
+    const uint64_t* ids = ids_.data() + group * S_;
+    for (uint32_t s = 0; s < S_; ++s)
+        if (lens[s])
+            (*msgs)[ids[s]] = std::string(reinterpret_cast<const char*>(bytes.data()) + (size_t)s * RAFTHIP_HEARTBEAT_STRIDE, lens[s]);
+    return RAFTHIP_OK;
+}
+
 int BatchProgressTracker::EnableProgress(uint32_t max_inflight, uint64_t max_inflight_bytes) {
     int rc = Flush();
     if (rc) return rc;

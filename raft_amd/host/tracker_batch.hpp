@@ -14,6 +14,7 @@
 
 #include <map>
 #include <set>
+#include <string>
 #include <unordered_map>
 #include <vector>
 
@@ -113,6 +114,13 @@ class BatchProgressTracker {
     int CheckQuorum(std::vector<uint8_t>* active);
     // sendHeartbeat's commit for peer `id` (raft.go:669-685), after MaybeCommit().
     int HeartbeatCommit(uint64_t group, uint64_t id, uint64_t* commit);
+
+    // bcastHeartbeat for one led group (raft.go:698-716 -> sendHeartbeat :669-685 -> r.send :502-533), after
+    // MaybeCommit(): *msgs receives, per peer id but the leader's own, the serialized raftpb.Message
+    // {Type: MsgHeartbeat, To: id, From: self, Term: term, Commit: min(Match, committed), Context: ctx} exactly as
+    // Message.Marshal writes it (raftpb/raft.pb.go:937-1025).  ctx is the last pending ReadIndex request
+    // context (readOnly.lastPendingRequestCtx, read_only.go:116-121), at most 8 bytes here; empty = nil.
+    int BcastHeartbeat(uint64_t group, uint64_t term, const std::string& ctx, std::map<uint64_t, std::string>* msgs);
 
     // ---- per-peer replication state: tracker.Progress + tracker.Inflights ----------
     // (tracker/progress.go:30-98, tracker/inflights.go:28-40)

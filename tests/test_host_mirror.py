@@ -430,3 +430,40 @@ def test_tracker_progress_scenarios():
         if one_batch:
             assert views[-1] == views[len(steps) - 1], sc["src"]
             assert len(acts[-1].split()[1].split(",")) == len(steps)
+
+
+@pytest.mark.gpu
+def test_tracker_bcast_heartbeat(oracle):
+    """BcastHeartbeat through the host mirror: the heartbeats the reference's tests show
+    (tests/golden/scenarios.json heartbeat_commit_cases), each as the bytes Message.Marshal writes — compared with
+    the oracle's marshaller and parsed back; with and without a pending ReadIndex context; a group in the middle of
+    a tracker with other groups around it."""
+    import json
+    from oracle import pyoracle as po
+    with open(os.path.join(gu.HERE, "golden", "scenarios.json")) as fh:
+        cases = json.load(fh)["heartbeat_commit_cases"]
+    G, S = len(cases) + 2, 4
+    script, want = ["tracker %d %d" % (G, S)], ["tracker ok"]
+    for k, c in enumerate(cases):
+        g = k + 1
+        script.append("setconfig %d in=%s out= learners=" % (g, ids(c["ids"])))
+        script.append("leader %d %d 1 %d" % (g, c["leader"], max(c["match"])))
+        for i, mt in zip(c["ids"], c["match"]):
+            script.append("ack %d %d %d" % (g, i, mt))
+        script.append("setcommitted %d %d" % (g, c["committed"]))
+        for ctx in (b"", b"rd-%d" % k):
+            script.append(("heartbeats %d %d %s" % (g, c["term"], ctx.hex())).rstrip())
+            for peer in sorted(int(p) for p in c["want"]):
+                blob = po.message_marshal(type=8, to=peer, frm=c["leader"], term=c["term"], commit=c["want"][str(peer)],
+                                          context=ctx or None)
+                want.append("heartbeat %d %d %s" % (g, peer, blob.hex()))
+                rc, f = oracle.message_unmarshal(blob)
+                assert rc == 0 and (f["to"], f["from"], f["term"], f["commit"]) == (peer, c["leader"], c["term"], c["want"][str(peer)])
+            want.append("heartbeats-done %d" % len(c["want"]))
+    # a group that is not led here has nothing to send; a context longer than the engine tracks is an error
+    script += ["setconfig 0 in=1,2,3 out= learners=", "follower 0", "heartbeats 0 1", "heartbeats 1 1 %s" % ("ab" * 9)]
+    want += ["heartbeats-done 0"]
+    out = [l for l in run_cli("\n".join(script) + "\n") if not l.endswith(" ok")][0:]
+    want = [l for l in want if not l.endswith(" ok")]
+    assert out[:len(want)] == want, [(a, b) for a, b in zip(out, want) if a != b][:3]
+    assert len(out) == len(want) + 1 and out[-1].startswith("error "), out[-1]
