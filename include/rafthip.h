@@ -414,6 +414,25 @@ int rafthip_upload_first_index(rafthip_engine *e, uint64_t first, uint64_t count
 int rafthip_step_progress(rafthip_engine *e, const rafthip_msg *msgs, const uint64_t *aux, uint64_t n,
                           uint8_t *actions);
 
+/* bcastAppend as a plan — raft.go:689-696: for every Progress row of groups
+ * [first, first+count) but the leaders' own, what maybeSendAppend(to,
+ * sendIfEmpty) (raft.go:600-666) decides to send right now, without building
+ * the message: plan[s*stride + g] is one of RAFTHIP_SEND_*; next (may be NULL)
+ * receives pr.Next of the same row — a MsgApp's Index is Next-1 and its entries
+ * start at Next.  The decision reads IsPaused (tracker/progress.go:225-236),
+ * Inflights.Full (inflights.go:131-133), RecentActive, raftLog.firstIndex()
+ * (rafthip_upload_first_index) and lastIndex (term_last).  Rows outside the
+ * config and groups without a self bit (not led here) plan nothing.  After a
+ * send the host submits RAFTHIP_MSG_SENT_APP / _SENT_SNAP records as before
+ * (UpdateOnEntriesSend / BecomeSnapshot, raft.go:645,653).  Both outputs host or
+ * device memory. */
+#define RAFTHIP_SEND_NONE 0
+#define RAFTHIP_SEND_APPEND 1   /* MsgApp with entries from pr.Next, as many as maxMsgSize admits */
+#define RAFTHIP_SEND_EMPTY 2    /* MsgApp without entries: conveys the commit index */
+#define RAFTHIP_SEND_SNAPSHOT 3 /* term(Next-1) or the entries are gone: MsgSnap (raft.go:625-650) */
+int rafthip_plan_appends(rafthip_engine *e, uint64_t first, uint64_t count, int send_if_empty, uint8_t *plan,
+                         uint64_t *next, uint64_t stride);
+
 /* rafthip_step_progress for a tick whose responses are dense — in steady state
  * every follower of every group acks and answers its heartbeat every tick:
  *   acks[s*ack_stride + g]  acknowledged index + 1 of a non-reject MsgAppResp from

@@ -168,3 +168,14 @@ func (b *BatchEngine) Heartbeats(bytes, lens []uint8) error {
 	return hipErr(C.rafthip_emit_heartbeats(b.e, 0, C.uint64_t(b.groups), (*C.uint8_t)(unsafe.Pointer(&bytes[0])),
 		(*C.uint8_t)(unsafe.Pointer(&lens[0]))))
 }
+
+// PlanAppends: bcastAppend as a plan (raft.go:689-696): plan[s*groups+g] is what maybeSendAppend(to, sendIfEmpty)
+// decides for the peer in slot s of group g (C.RAFTHIP_SEND_*), next[s*groups+g] its pr.Next.
+func (b *BatchEngine) PlanAppends(sendIfEmpty bool, plan []uint8, next []uint64) error {
+	sie := C.int(0)
+	if sendIfEmpty {
+		sie = 1
+	}
+	return hipErr(C.rafthip_plan_appends(b.e, 0, C.uint64_t(b.groups), sie, (*C.uint8_t)(unsafe.Pointer(&plan[0])),
+		(*C.uint64_t)(unsafe.Pointer(&next[0])), C.uint64_t(b.groups)))
+}

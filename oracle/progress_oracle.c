@@ -429,3 +429,78 @@ ORACLE_API void oracle_step_progress(uint64_t G, int nslots, uint64_t stride, ui
     free(buf);
     free(cnt);
 }
+
+/* ------------------------------------------------------------------------ */
+/* bcastAppend as a plan: what maybeSendAppend decides, message by message.    */
+/* ------------------------------------------------------------------------ */
+
+enum { SEND_NONE = 0, SEND_APPEND = 1, SEND_EMPTY = 2, SEND_SNAPSHOT = 3 };
+
+/* log.go:381-397 — does raftLog.term(i) return an error?  (the valid range is
+ * [firstIndex-1, lastIndex]) */
+static int log_term_fails(uint64_t i, uint64_t first_index, uint64_t last_index) {
+    if (i + 1 < first_index) return 1; /* ErrCompacted */
+    if (i > last_index) return 1;      /* ErrUnavailable */
+    return 0;
+}
+
+/* log.go:409-414 + mustCheckOutOfBounds :543-557 — raftLog.entries(i, maxSize):
+ * *n_entries > 0 iff at least one entry comes back (a size limit never returns
+ * zero entries); returns 1 on ErrCompacted. */
+static int log_entries(uint64_t i, uint64_t first_index, uint64_t last_index, int *n_entries) {
+    *n_entries = 0;
+    if (i > last_index) return 0; /* nil, nil */
+    if (i < first_index) return 1;
+    *n_entries = 1;
+    return 0;
+}
+
+/* raft.go:600-666 — maybeSendAppend(to, sendIfEmpty), up to the point where
+ * the message would be built. */
+static int maybe_send_append(const progress *pr, uint64_t first_index, uint64_t last_log_index, int send_if_empty) {
+    if (is_paused(pr)) return SEND_NONE;
+    uint64_t last_index = pr->next - 1, next_index = pr->next;
+    int errt = log_term_fails(last_index, first_index, last_log_index);
+    int n_ents = 0, erre = 0;
+    if (pr->state != STATE_REPLICATE || !inflights_full(&pr->ins))
+        erre = log_entries(next_index, first_index, last_log_index, &n_ents);
+    if (n_ents == 0 && !send_if_empty) return SEND_NONE;
+    if (errt || erre) { /* send snapshot if we failed to get term or entries */
+        if (!pr->recent_active) return SEND_NONE;
+        return SEND_SNAPSHOT;
+    }
+    return n_ents > 0 ? SEND_APPEND : SEND_EMPTY;
+}
+
+/*
+ * raft.go:689-696 — bcastAppend for G groups: Visit every Progress but r.id's.
+ * rows = the slots that hold a Progress (NULL: all of them); a group without a
+ * self bit is not led here and plans nothing.  plan is [nslots][stride].
+ */
+ORACLE_API void oracle_plan_appends(uint64_t G, int nslots, uint64_t stride, const uint64_t *next,
+                                    const uint8_t *pstate, const uint32_t *infl_meta, const uint64_t *infl_bytes,
+                                    int cap, uint64_t max_bytes, const void *rows, const void *self_mask,
+                                    const void *active, int mask_bytes, const uint64_t *first_index,
+                                    const uint64_t *last_index, int send_if_empty, uint8_t *plan) {
+    for (uint64_t g = 0; g < G; g++) {
+        uint64_t self = load_mask(self_mask, mask_bytes, g);
+        uint64_t have = rows ? load_mask(rows, mask_bytes, g) : ~0ULL;
+        uint64_t act = load_mask(active, mask_bytes, g);
+        for (int s = 0; s < nslots; s++) {
+            uint64_t cell = (uint64_t)s * stride + g;
+            plan[cell] = SEND_NONE;
+            if (self == 0 || ((self >> s) & 1) || !((have >> s) & 1)) continue;
+            progress pr;
+            memset(&pr, 0, sizeof pr);
+            pr.next = next[cell];
+            pr.state = pstate[cell] & 3;
+            pr.msg_app_flow_paused = (pstate[cell] >> 2) & 1;
+            pr.recent_active = (int)((act >> s) & 1);
+            pr.ins.count = (int)(infl_meta[cell] >> 16);
+            pr.ins.bytes = infl_bytes[cell];
+            pr.ins.size = cap;
+            pr.ins.max_bytes = max_bytes;
+            plan[cell] = (uint8_t)maybe_send_append(&pr, first_index[g], last_index[g], send_if_empty);
+        }
+    }
+}

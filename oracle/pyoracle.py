@@ -593,3 +593,23 @@ def step_progress(pl, cap, max_bytes, active, acks, last_index, first_index, msg
                                _vp(_chk(first_index, np.uint64)), _vp(msgs), _vp(aux) if aux is not None else None,
                                n, limit, _vp(actions))
     return actions
+
+
+SEND_NONE, SEND_APPEND, SEND_EMPTY, SEND_SNAPSHOT = 0, 1, 2, 3
+
+
+def plan_appends(pl, cap, max_bytes, rows, self_mask, active, first_index, last_index, send_if_empty=True):
+    """bcastAppend as a plan: uint8 [S][G], what maybeSendAppend(to, sendIfEmpty) decides for every Progress row
+    (rows: slot bitmask of the rows that exist per group, None = all)."""
+    S, G = pl["next"].shape
+    plan = np.zeros((S, G), dtype=np.uint8)
+    f = lib().oracle_plan_appends
+    f.restype = None
+    f.argtypes = [C.c_uint64, C.c_int, C.c_uint64] + [C.c_void_p] * 4 + [C.c_int, C.c_uint64] + [C.c_void_p] * 3 + [
+        C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    self_mask, active = _chk(self_mask), _chk(active)
+    f(G, S, pl["next"].strides[0] // 8, _vp(_chk(pl["next"], np.uint64)), _vp(_chk(pl["pstate"], np.uint8)),
+      _vp(_chk(pl["infl_meta"], np.uint32)), _vp(_chk(pl["infl_bytes"], np.uint64)), cap, max_bytes,
+      _vp(_chk(rows)) if rows is not None else None, _vp(self_mask), _vp(active), active.dtype.itemsize,
+      _vp(_chk(first_index, np.uint64)), _vp(_chk(last_index, np.uint64)), int(bool(send_if_empty)), _vp(plan))
+    return plan

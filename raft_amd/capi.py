@@ -44,7 +44,7 @@ SYMBOLS = [
     "rafthip_read_inflights", "rafthip_upload_first_index", "rafthip_step_progress", "rafthip_step_wire",
     "rafthip_merge_acks", "rafthip_host_alloc", "rafthip_host_free",
     "rafthip_record_votes", "rafthip_read_votes", "rafthip_step_dense", "rafthip_upload_campaign",
-    "rafthip_emit_heartbeats",
+    "rafthip_emit_heartbeats", "rafthip_plan_appends",
 ]
 MSG_VOTE_RESP, MSG_PRE_VOTE_RESP = 6, 18
 
@@ -59,6 +59,7 @@ WIRE_STATUSES = 10
  WIRE_BAD_GROUP, WIRE_NEEDS_LOG, WIRE_VOTE) = range(10)
 MSG_NEEDS_HOST = 0xFE
 HEARTBEAT_STRIDE = 72
+SEND_NONE, SEND_APPEND, SEND_EMPTY, SEND_SNAPSHOT = 0, 1, 2, 3
 MSGF_READ_CTX, MSGF_HAS_CTX = 1, 2
 
 
@@ -163,6 +164,7 @@ def load_library():
         "rafthip_upload_read_ctx": (i32, [vp, u64, u64, vp, vp]),
         "rafthip_upload_campaign": (i32, [vp, u64, u64, vp]),
         "rafthip_emit_heartbeats": (i32, [vp, u64, u64, vp, vp]),
+        "rafthip_plan_appends": (i32, [vp, u64, u64, i32, vp, vp, u64]),
         "rafthip_ingest_wire": (i32, [vp, vp, vp, vp, u64, vp, vp, vp]),
         "rafthip_progress_config": (i32, [vp, u32, u64]),
         "rafthip_upload_progress": (i32, [vp, u64, u64, vp, vp, vp, u64]),
@@ -485,6 +487,14 @@ class Engine:
         out = np.empty((self.S, count), dtype=np.uint64) if download else None
         _check(self._L.rafthip_heartbeat_commit(self._h, first, count, _ptr(out), count))
         return out
+
+    def plan_appends(self, send_if_empty=True, first=0, count=None, want_next=True):
+        """bcastAppend as a plan -> (uint8 [S][count] SEND_*, uint64 [S][count] Next or None)."""
+        first, count = self._range(first, count)
+        plan = np.empty((self.S, count), dtype=np.uint8)
+        nxt = np.empty((self.S, count), dtype=np.uint64) if want_next else None
+        _check(self._L.rafthip_plan_appends(self._h, first, count, int(bool(send_if_empty)), _ptr(plan), _ptr(nxt), count))
+        return plan, nxt
 
     def emit_heartbeats(self, first=0, count=None):
         """bcastHeartbeat as bytes -> (uint8 [S][count][HEARTBEAT_STRIDE] zero-padded messages, uint8 [S][count] lengths)."""

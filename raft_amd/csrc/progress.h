@@ -417,6 +417,75 @@ __global__ __launch_bounds__(kBlock) void k_progress_dense(ProgPlanes pl, u64 fi
     }
 }
 
+// ---------------------------------------------------------------------------
+// K11 — bcastAppend as a plan (raft.go:689-696): which peers of a led group get
+// an append now, and of which kind — maybeSendAppend's decision
+// (raft.go:600-666) without building the message:
+//   IsPaused()                                     -> none      (:602-604)
+//   errt = term(Next-1) fails: compacted / beyond lastIndex      (:606-607, log.go:381-397)
+//   entries wanted unless a throttled StateReplicate (:617-619); raftLog.entries(Next):
+//       Next > lastIndex -> none, no error; Next < firstIndex -> ErrCompacted (log.go:409-414,543-557)
+//   no entries and !sendIfEmpty                    -> none      (:621-623)
+//   errt or erre: a snapshot, if RecentActive      -> snapshot / none  (:625-650)
+//   otherwise a MsgApp, with entries or empty      -> append / empty   (:652-665)
+// Lane = group, loop over slots; records, first / last index and the bit
+// planes are coalesced streams.  The leader's own row, rows outside the config
+// and groups without a self bit (not led here) get none.
+// ---------------------------------------------------------------------------
+enum : uint8_t { kSendNone = 0, kSendAppend = 1, kSendEmpty = 2, kSendSnapshot = 3 };  // = RAFTHIP_SEND_*
+
+__device__ __forceinline__ uint8_t plan_append(u64 next, u32 state, bool paused, bool full, bool recent_active,
+                                               u64 first_index, u64 last_index, bool send_if_empty) {
+    if (state == kStateSnapshot || paused) return kSendNone;  // IsPaused, progress.go:225-236
+    const u64 li = next - 1;
+    const bool errt = li + 1 < first_index || li > last_index;
+    bool have = false, erre = false;
+    if (state != kStateReplicate || !full) {
+        if (next > last_index) {
+        } else if (next < first_index) {
+            erre = true;
+        } else {
+            have = true;
+        }
+    }
+    if (!have && !send_if_empty) return kSendNone;
+    if (errt || erre) return recent_active ? kSendSnapshot : kSendNone;
+    return have ? kSendAppend : kSendEmpty;
+}
+
+template <typename MaskT>
+__global__ __launch_bounds__(kBlock) void k_plan_appends(ProgPlanes pl, u64 first, u64 count, u32 S,
+                                                         const MaskT* __restrict__ in_mask /* NULL: every slot holds a row */,
+                                                         const MaskT* __restrict__ out_mask,
+                                                         const MaskT* __restrict__ learner_mask /* may be NULL */,
+                                                         const MaskT* __restrict__ self_mask,
+                                                         const MaskT* __restrict__ active,
+                                                         const u64* __restrict__ first_index,
+                                                         const u64* __restrict__ last_index, bool send_if_empty,
+                                                         uint8_t* __restrict__ plan, u64* __restrict__ next_out,
+                                                         u64 out_stride) {
+    const u64 i = (u64)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= count) return;
+    const u64 g = first + i;
+    const u64 self = (u64)self_mask[g];
+    const u64 have_row = in_mask ? ((u64)in_mask[g] | (u64)out_mask[g] | (learner_mask ? (u64)learner_mask[g] : 0)) : ~0ull;
+    const u64 act = (u64)active[g];
+    const u64 fi = first_index[g], la = last_index[g];
+    for (u32 s = 0; s < S; ++s) {
+        const u64* rw = reinterpret_cast<const u64*>(pl.rec + (u64)s * pl.stride + g);
+        const Vec<u64, 2> r0 = load_vec<u64, 2>(rw), r1 = load_vec<u64, 2>(rw + 2);
+        const u32 meta = (u32)r1.v[1];
+        const u32 icount = (meta >> 14) & 0x7FFFu;
+        const bool full = icount == pl.cap || (pl.max_bytes != 0 && r1.v[0] >= pl.max_bytes);  // inflights.go:131-133
+        uint8_t out = kSendNone;
+        if (self != 0 && !((self >> s) & 1ull) && ((have_row >> s) & 1ull))
+            out = plan_append(r0.v[0], (meta >> 29) & 3u, (meta >> 31) != 0, full, ((act >> s) & 1ull) != 0, fi, la,
+                              send_if_empty);
+        plan[(u64)s * out_stride + i] = out;
+        if (next_out) next_out[(u64)s * out_stride + i] = r0.v[0];
+    }
+}
+
 // ---- SoA <-> record conversion for the upload / read entry points -----------
 // (the C ABI speaks [slot][group] planes like every other call)
 

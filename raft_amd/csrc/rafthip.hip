@@ -1512,6 +1512,71 @@ int rafthip_step_dense(rafthip_engine* e, uint64_t first, uint64_t count, const 
     return RAFTHIP_OK;
 }
 
+static_assert(kSendNone == RAFTHIP_SEND_NONE && kSendAppend == RAFTHIP_SEND_APPEND && kSendEmpty == RAFTHIP_SEND_EMPTY &&
+                  kSendSnapshot == RAFTHIP_SEND_SNAPSHOT,
+              "send plan constants");
+
+int rafthip_plan_appends(rafthip_engine* e, uint64_t first, uint64_t count, int send_if_empty, uint8_t* plan,
+                         uint64_t* next, uint64_t stride) {
+    int rc = need_progress(e);
+    if (rc || (rc = check_range(e, first, count))) return rc;
+    if (!plan) return fail(RAFTHIP_EINVAL, "plan is NULL");
+    if (stride < count) return fail(RAFTHIP_EINVAL, "stride %llu < count %llu", (u64)stride, (u64)count);
+    if (count == 0) return RAFTHIP_OK;
+    DeviceGuard guard(e->device);
+    const size_t plane_b = (size_t)e->stride * e->mbytes;
+    if ((rc = ensure(e, e->active, plane_b))) return rc;
+    if ((rc = ensure(e, e->self_mask, plane_b))) return rc;
+    const bool every_slot = e->uniform && e->uniform_voters > 0;
+    if (!every_slot && (rc = ensure_masks(e))) return rc;
+    const bool plan_host = !is_device_ptr(plan), next_host = next && !is_device_ptr(next);
+    uint8_t* d_plan = plan;
+    u64* d_next = reinterpret_cast<u64*>(next);
+    u64 d_stride = stride;
+    if (plan_host || next_host) {  // staged outputs are packed at row pitch `count`
+        if (!plan_host || (next && !next_host))
+            return fail(RAFTHIP_EINVAL, "plan and next must both be host or both be device memory");
+        d_stride = count;
+        if ((rc = stage_reserve(e, kStageActions, (size_t)count * e->S))) return rc;
+        d_plan = static_cast<uint8_t*>(e->stage_buf[kStageActions]);
+        if (next) {
+            if ((rc = stage_reserve(e, kStageAux, (size_t)count * e->S * sizeof(u64)))) return rc;
+            d_next = static_cast<u64*>(e->stage_buf[kStageAux]);
+        }
+    }
+    e->pp.match = e->match;
+    const u32 blocks = (u32)((count + kBlock - 1) / kBlock);
+#define RAFTHIP_PLAN(MT)                                                                                            \
+    hipLaunchKernelGGL((k_plan_appends<MT>), dim3(blocks), dim3(kBlock), 0, e->stream, e->pp, (u64)first, (u64)count, \
+                       e->S, every_slot ? nullptr : static_cast<const MT*>(e->in_mask),                              \
+                       static_cast<const MT*>(e->out_mask), static_cast<const MT*>(e->learner_mask),                  \
+                       static_cast<const MT*>(e->self_mask), static_cast<const MT*>(e->active),                       \
+                       static_cast<const u64*>(e->first_index), static_cast<const u64*>(e->term_last),                \
+                       send_if_empty != 0, d_plan, d_next, d_stride)
+    if (e->mbytes == 1) {
+        RAFTHIP_PLAN(uint8_t);
+    } else if (e->mbytes == 2) {
+        RAFTHIP_PLAN(uint16_t);
+    } else if (e->mbytes == 4) {
+        RAFTHIP_PLAN(uint32_t);
+    } else {
+        RAFTHIP_PLAN(uint64_t);
+    }
+#undef RAFTHIP_PLAN
+    HIP_TRY(hipGetLastError());
+    e->stats.groups_evaluated += count;
+    if (plan_host) {
+        if ((rc = copy_rows(e, plan, stride, d_plan, count, count, e->S))) return rc;
+        e->stats.bytes_downloaded += count * e->S;
+        if (next) {
+            if ((rc = copy_rows(e, next, stride * 8, d_next, count * 8, count * 8, e->S))) return rc;
+            e->stats.bytes_downloaded += count * 8 * e->S;
+        }
+        HIP_TRY(hipStreamSynchronize(e->stream));
+    }
+    return RAFTHIP_OK;
+}
+
 int rafthip_step_progress(rafthip_engine* e, const rafthip_msg* msgs, const uint64_t* aux, uint64_t n,
                           uint8_t* actions) {
     int rc = need_progress(e);

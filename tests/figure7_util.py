@@ -10,6 +10,7 @@ A driver holds one 7-voter group (or many copies of it) and offers
     become_leader(self_id, last_index, first_index, committed)   # raft.go:933-972
     step(kind, id, **fields) -> action byte                      # kind: appended | sent_app | app_resp
     progress(id) -> {"state", "match", "next", "is_paused"}
+    plan(id) -> SEND_* of maybeSendAppend(id, true) right now
     maybe_commit() -> commit index after raft.maybeCommit
 so that the oracle (tests/test_figure7_cpu.py) and the engine (tests/test_gpu_figure7.py) replay the
 same steps."""
@@ -93,6 +94,7 @@ def replay(fx, drv):
             assert log.term(ev["prev"]) == ev["prev_term"], where
             assert committed == ev["commit"], where
             assert ev["prev"] + ev["entries"] <= log.last, where
+            assert drv.plan(ev["to"]) == (po.SEND_APPEND if ev["entries"] else po.SEND_EMPTY), where
             drv.step("sent_app", ev["to"], entries=ev["entries"], index=ev["prev"] + ev["entries"], nbytes=ev["entries"])
         elif ev["ev"] == "recv":
             before = drv.progress(ev["from"])
@@ -125,6 +127,13 @@ def replay(fx, drv):
                 assert c == committed, (where, c, committed)
         elif ev["ev"] == "commit":
             assert committed == ev["value"], where
+            # bcastAppend (raft.go:1503-1504): the sends that follow are exactly the peers the plan names
+            sent, j = [], k + 1
+            while j < len(evs) and evs[j]["ev"] == "send":
+                sent.append(evs[j]["to"])
+                j += 1
+            planned = [i for i in ids if i != me and drv.plan(i) != po.SEND_NONE]
+            assert planned == sent, (where, planned, sent)
     for i in ids:
         st = drv.progress(i)
         assert (st["state"], st["match"], st["next"]) == (po.STATE_REPLICATE, log.last, log.last + 1), (i, st)

@@ -22,6 +22,7 @@ class po:  # the event / action / state numbers (= oracle.pyoracle's and raft_am
     EV_APPENDED, EV_SENT_APP, EV_SENT_SNAP, EV_NEEDS_HOST = 0xF0, 0xF1, 0xF2, 0xFE
     ACT_SEND_APPEND, ACT_UPDATED, ACT_WAS_PAUSED, ACT_CAUGHT_UP, ACT_ERROR, ACT_DEFERRED, ACT_DROPPED = 1, 2, 4, 8, 32, 64, 128
     STEP_LIMIT = 64
+    SEND_NONE, SEND_APPEND, SEND_EMPTY, SEND_SNAPSHOT = 0, 1, 2, 3
 
     @staticmethod
     def progress_planes(S, G, cap):
@@ -118,6 +119,17 @@ def check_actions(step, act, where):
         for a in step["actions"]:
             want |= ACT[a]
         assert act == want, (where, act, want)
+
+
+def sent_plan(step, src):
+    """A send record of a fixture scenario is a send the reference performed (maybeSendAppend, raft.go:600-666):
+    the plan computed from the state just before it must name that send.  None = no statement (other events;
+    raft_snap_test.go calls BecomeSnapshot by hand, :76,:98,:121, without going through maybeSendAppend)."""
+    if step["ev"] == "sent_app":
+        return po.SEND_APPEND if step["entries"] else po.SEND_EMPTY
+    if step["ev"] == "sent_snap" and not src.startswith("raft_snap_test.go"):
+        return po.SEND_SNAPSHOT
+    return None
 
 
 def random_planes(rng, S, G, cap, max_bytes):

@@ -37,7 +37,7 @@ class OracleDriver:
         self.active, self.acks = pu.mask_planes(S, 1)
         self.last = np.array([last], dtype=np.uint64)
         self.first = np.array([first], dtype=np.uint64)
-        self.committed, self.term = committed, term
+        self.committed, self.term, self.me = committed, term, me
 
     def step(self, kind, who, index=0, reject=False, hint=0, log_term=0, resolved=0, entries=0, nbytes=0):
         m = np.zeros(1, dtype=self.py.MSG_DTYPE)
@@ -60,6 +60,10 @@ class OracleDriver:
 
     def progress(self, who):
         return pu.cell_state(self.pl, self.cap, 0, self.slot[who], 0)
+
+    def plan(self, who):
+        self_mask = np.array([1 << self.slot[self.me]], dtype=np.uint8)
+        return int(self.py.plan_appends(self.pl, self.cap, 0, None, self_mask, self.active, self.first, self.last)[self.slot[who], 0])
 
     def maybe_commit(self):
         mci = int(self.o.batch_committed(self.pl["match"], uniform_voters=self.S)[0])

@@ -72,6 +72,7 @@ class EngineDriver:
         e.upload_ids(self.ids)
         e.upload_term(np.full(G, term, dtype=np.uint64))
         e.upload_read_ctx(np.zeros(G, dtype=np.uint64), np.zeros(G, dtype=np.uint8))
+        e.upload_self((np.uint64(1) << mine.astype(np.uint64)).astype(np.uint8))
         self.term, self.me = term, me
 
     def step(self, kind, who, index=0, reject=False, hint=0, log_term=0, resolved=0, entries=0, nbytes=0):
@@ -106,6 +107,13 @@ class EngineDriver:
         for k in ("match", "next", "pstate"):
             self.same(got[k][s, np.arange(self.G)])
         return cells[0]
+
+    def plan(self, who):
+        plan, nxt = self.e.plan_appends()
+        s = self.slots(who)
+        got = self.same(plan[s, np.arange(self.G)])
+        assert self.same(plan[self.slots(self.me), np.arange(self.G)]) == capi.SEND_NONE  # never to itself
+        return got
 
     def maybe_commit(self):
         before = self.e.read_commit()

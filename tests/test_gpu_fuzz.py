@@ -69,7 +69,7 @@ def test_random_call_sequences(oracle, S, G, seed):
         e.upload_read_ctx(wire["cw"], wire["cl"])
         e.upload_campaign(wire["camp"])
         for step in range(170):
-            op = int(rng.integers(0, 25))
+            op = int(rng.integers(0, 26))
             checked[0] += 10 <= op < 16
             a, n = rng_range()
             if op == 0:
@@ -196,6 +196,14 @@ def test_random_call_sequences(oracle, S, G, seed):
                 assert np.array_equal(status, ws) and np.array_equal(counts, wc) and np.array_equal(msgs, wm), step
                 assert np.array_equal(e.read_votes(), sh["votes"]) and np.array_equal(e.read_match(), sh["match"]), step
                 assert np.array_equal(e.read_active(), sh["active"]) and np.array_equal(e.read_acks(), sh["acks"]), step
+            elif op == 25:
+                sie = bool(rng.integers(0, 2))
+                plan, nxt = e.plan_appends(send_if_empty=sie, first=a, count=n)
+                rows = None if uniform[0] else (sh["m0"] | sh["m1"] | sh["ml"])  # uniform: every slot holds a row
+                if uniform[0] == 0:
+                    rows = np.zeros(G, mdt)
+                want = po.plan_appends(pl, cap, max_bytes, rows, sh["self"], sh["active"], first_index, sh["tl"], sie)
+                assert np.array_equal(plan, want[:, a:a + n]) and np.array_equal(nxt, pl["next"][:, a:a + n]), step
             elif op == 24:
                 out, lens = e.emit_heartbeats(first=a, count=n)
                 want, wlen = oracle.bcast_heartbeat(sh["match"], sh["commit"], wire["ids"], wire["term"], wire["cw"], wire["cl"],

@@ -61,7 +61,18 @@ def test_reference_scenarios(k):
     recs, auxs = [], []
     with raft_amd.Engine(G, S) as e:
         upload_state(e, pl, cap, mb, active, acks, last, first)
+        self_mask = np.zeros(G, dtype=active.dtype)
+        self_mask[group] = 1  # the scenario's group is led from slot 0
+        e.upload_self(self_mask)
+        e.set_uniform_config(S)
         for i, st in enumerate(steps):
+            want = pu.sent_plan(st, sc["src"])
+            if want is not None:  # a send the reference performed from this state (maybeSendAppend, raft.go:600-666)
+                plan, nxt = e.plan_appends(first=group, count=1)
+                assert int(plan[slot, 0]) == want and int(plan[0, 0]) == capi.SEND_NONE, (sc["src"], i, plan[:, 0])
+                assert int(nxt[slot, 0]) == int(e.read_progress()["next"][slot, group])
+                if want == capi.SEND_EMPTY:
+                    assert int(e.plan_appends(send_if_empty=False, first=group, count=1)[0][slot, 0]) == capi.SEND_NONE
             m, aux = pu.event(st, group, slot)
             recs.append(m)
             auxs.append(aux)
@@ -69,7 +80,10 @@ def test_reference_scenarios(k):
             pu.check_actions(st, int(act[0]), (sc["src"], i))
             got = e.read_progress()
             got["match"] = e.read_match()
-            pu.check_expect(st, pu.cell_state(got, cap, mb, slot, group), (sc["src"], i))
+            cell = pu.cell_state(got, cap, mb, slot, group)
+            pu.check_expect(st, cell, (sc["src"], i))
+            if cell["is_paused"]:
+                assert int(e.plan_appends(first=group, count=1, want_next=False)[0][slot, 0]) == capi.SEND_NONE
         final = e.read_progress()
         final["match"] = e.read_match()
         if len(steps) <= capi.STEP_LIMIT and not any(st["ev"] == "appended" for st in steps):
@@ -243,3 +257,56 @@ def test_dense_step_equals_the_event_stream(S, cap, mb, first_off):
         ev, _, _ = dense_as_events(plane, np.zeros(cnt, dtype=mdt), np.zeros(cnt, dtype=mdt), S, cnt, first_off)
         po.step_progress(pl, cap, mb, active, acks_bits, last, firsti, ev, None, limit=1 << 30)
         assert_state(e, pl, active, acks_bits, last)
+
+
+@pytest.mark.parametrize("S,cap,mb,uniform", [(3, 4, 0, True), (5, 2, 100, False), (9, 1, 0, True), (16, 8, 300, False),
+                                              (33, 3, 0, False), (64, 2, 60, True), (5, 0, 0, False)])
+def test_plan_appends_random(S, cap, mb, uniform):
+    """rafthip_plan_appends = maybeSendAppend's decision for every Progress row (raft.go:600-666, bcastAppend
+    :689-696) against the oracle: every state, paused or not, full and empty windows, Next around the compacted
+    prefix and past the log's end, inactive peers, rows outside the config, groups not led here; both
+    sendIfEmpty values; a partial range; device outputs with a row pitch wider than the range."""
+    import golden_util as gu
+    from test_gpu_parity import rand_masks
+    rng = np.random.default_rng(2500 + S)
+    G = 3011
+    pl = pu.random_planes(rng, S, G, cap, mb)
+    last = pl["match"].max(axis=0) + rng.integers(0, 6, size=G).astype(np.uint64)
+    first = np.where(rng.random(G) < 0.5, 0, pl["match"].min(axis=0) + rng.integers(0, 8, size=G).astype(np.uint64)).astype(np.uint64)
+    mdt = gu.mask_dtype(S)
+    full = mdt((1 << S) - 1 if S < 64 else gu.U64MAX)
+    active = rand_masks(rng, S, G, joint_frac=0, empty_frac=0.1)[0]
+    self_mask = (np.uint64(1) << rng.integers(0, S, size=G).astype(np.uint64)).astype(mdt)
+    self_mask[rng.random(G) < 0.1] = 0
+    with raft_amd.Engine(G, S) as e:
+        upload_state(e, pl, cap, mb, active, np.zeros(G, dtype=mdt), last, first)
+        e.upload_self(self_mask)
+        if uniform:
+            e.set_uniform_config(max(S - 2, 1))
+            rows = None
+        else:
+            m0, m1 = rand_masks(rng, S, G)
+            lrn = (~(m0 | m1)) & full & rand_masks(rng, S, G, joint_frac=0, empty_frac=0.3)[0]
+            e.upload_config(m0, m1, lrn)
+            rows = m0 | m1 | lrn
+        seen = np.zeros(4, dtype=np.int64)
+        for sie in (True, False):
+            want = po.plan_appends(pl, cap, mb, rows, self_mask, active, first, last, sie)
+            plan, nxt = e.plan_appends(send_if_empty=sie)
+            assert np.array_equal(plan, want) and np.array_equal(nxt, pl["next"])
+            seen += np.bincount(want.ravel(), minlength=4)
+            a, n = G // 3, G // 2
+            plan, nxt = e.plan_appends(send_if_empty=sie, first=a, count=n)
+            assert np.array_equal(plan, want[:, a:a + n]) and np.array_equal(nxt, pl["next"][:, a:a + n])
+        assert (seen > 0).all(), seen
+        import torch
+        dp = torch.full((S, G + 5), 0xEE, dtype=torch.uint8, device="cuda")
+        dn = torch.zeros((S, G + 5), dtype=torch.int64, device="cuda")
+        L = raft_amd.load_library()
+        assert L.rafthip_plan_appends(e._h, 0, G, 1, dp.data_ptr(), dn.data_ptr(), G + 5) == 0
+        e.synchronize()
+        want = po.plan_appends(pl, cap, mb, rows, self_mask, active, first, last, True)
+        assert np.array_equal(dp.cpu().numpy()[:, :G], want) and (dp.cpu().numpy()[:, G:] == 0xEE).all()
+        assert np.array_equal(dn.cpu().numpy().view(np.uint64)[:, :G], pl["next"])
+        # the plan reads, it never writes
+        assert_state(e, pl, active, np.zeros(G, dtype=mdt), last)

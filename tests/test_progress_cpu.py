@@ -117,13 +117,26 @@ def test_scenarios_step_by_step_and_in_one_batch(k):
     last = np.array([sc["last_index"]], dtype=np.uint64)
     first = np.array([sc["first_index"]], dtype=np.uint64)
     recs, auxs = [], []
+    def plan(send_if_empty=True):
+        # the scenario's Progress in slot 0 of a two-slot group led from slot 1
+        two = {k: np.concatenate([pl[k], np.zeros_like(pl[k])]) for k in ("next", "pstate", "infl_meta", "infl_bytes")}
+        return int(po.plan_appends(two, cap, mb, None, np.array([2], dtype=np.uint8), active, first, last, send_if_empty)[0, 0])
+
     for i, st in enumerate(steps):
+        want = pu.sent_plan(st, sc["src"])
+        if want is not None:  # the reference sent exactly this from the state the scenario is in
+            assert plan() == want, (sc["src"], i, plan(), want)
+            if want == po.SEND_EMPTY:
+                assert plan(send_if_empty=False) == po.SEND_NONE
         m, aux = pu.event(st)
         recs.append(m)
         auxs.append(aux)
         act = po.step_progress(pl, cap, mb, active, acks, last, first, m, aux)
         pu.check_actions(st, int(act[0]), (sc["src"], i))
-        pu.check_expect(st, pu.cell_state(pl, cap, mb), (sc["src"], i))
+        got = pu.cell_state(pl, cap, mb)
+        pu.check_expect(st, got, (sc["src"], i))
+        if got["is_paused"]:
+            assert plan() == po.SEND_NONE, (sc["src"], i)  # maybeSendAppend returns at :602-604
     # the same events as ONE batch end in the same state (stream order per Progress), while
     # the appended records of the batch apply first
     if len(steps) <= po.STEP_LIMIT and not any(st["ev"] == "appended" for st in steps):

@@ -140,6 +140,11 @@ int main(void) {
     OK(rafthip_step_progress(e, msgs, NULL, n, NULL));
     uint8_t *dact = buf((size_t)S * COUNT);
     OK(rafthip_step_dense(e, FIRST, COUNT, plane, COUNT, bits, bits, dact, COUNT));
+    uint8_t *plan = buf((size_t)S * COUNT);
+    OK(rafthip_plan_appends(e, FIRST, COUNT, 1, plan, next, COUNT));
+    OK(rafthip_plan_appends(e, FIRST, COUNT, 0, plan, NULL, COUNT));
+    for (size_t i = 0; i < (size_t)S * COUNT; i++)
+        if (plan[i] > RAFTHIP_SEND_SNAPSHOT) failures++;
     OK(rafthip_read_progress(e, FIRST, COUNT, state, next, pend, im, ib, COUNT));
     OK(rafthip_read_inflights(e, FIRST, COUNT, ri, rb, COUNT));
 

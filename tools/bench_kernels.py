@@ -284,6 +284,28 @@ def main():
             timed("k_merge_acks, dense plane, %.0f %% of cells acked (K5d)" % (100.0 * np.count_nonzero(plane) / plane.size),
                   "cell", Sv * G, 24, lambda: e.merge_acks(d_plane), setup=lambda: e.upload_match(low), iters=5)
         del plane, d_plane
+    # bcastAppend as a plan (K11): cfg5 shape, every group led from slot 0, steady state
+    if not args.only or args.only in "k_plan_appends (K11)":
+        import progress_util as pu
+        cap = 4
+        pl = pu.random_planes(rng, Sv, G, cap, 0)
+        d_plan = torch.empty((Sv, G), dtype=torch.uint8, device=dev)
+        d_next = torch.empty((Sv, G), dtype=torch.int64, device=dev)
+        L = raft_amd.load_library()
+        with raft_amd.Engine(G, Sv, stream=stream.cuda_stream) as e:
+            e.set_uniform_config(7)
+            e.progress_config(cap, 0)
+            e.upload_match(pl["match"])
+            e.upload_progress(pl["pstate"], pl["next"], pl["pending"])
+            e.upload_inflights(pl["infl_meta"], pl["infl_bytes"], pl["ring_index"], pl["ring_bytes"])
+            e.upload_term_range(np.zeros(G, dtype=np.uint64), pl["match"].max(axis=0) + np.uint64(16))
+            e.upload_first_index(np.zeros(G, dtype=np.uint64))
+            e.upload_active(np.full(G, 0x1FF, dtype=np.uint16))
+            e.upload_self(np.ones(G, dtype=np.uint16))
+            # per Progress row: the 32-byte record read + plan byte + Next written; per group 8 + 8 + 3 masks, shared by 9 rows
+            timed("k_plan_appends, plan + Next out (K11)", "row", Sv * G, 44,
+                  lambda: L.rafthip_plan_appends(e._h, 0, G, 1, d_plan.data_ptr(), d_next.data_ptr(), G))
+        del pl, d_plan, d_next
     # bcastHeartbeat as serialized bytes (K10): cfg5 shape, every group led here, ids 1..9, 8-byte ReadIndex context on half
     if not args.only or args.only in "k_emit_heartbeats (K10)":
         ids = np.tile(np.arange(1, Sv + 1, dtype=np.uint64)[:, None], (1, G))
