@@ -3,6 +3,7 @@
 2^22 groups x (7 voters + 2 learners), 2^24 serialized responses in ->
   rafthip_step_wire        decode + term gate + Progress lookup + Progress / Inflights stepping
   rafthip_commit_advance   quorum index + raftLog.maybeCommit's term guard, advanced pairs out
+  rafthip_plan_appends     bcastAppend as a plan: maybeSendAppend's decision per peer
   rafthip_emit_heartbeats  bcastHeartbeat as serialized MsgHeartbeat bytes (Commit = min(Match, committed) per peer)
   rafthip_check_quorum     QuorumActive + RecentActive reset
 Per-stage and whole-tick time from HIP events on the engine's stream; a development tool,
@@ -49,6 +50,8 @@ def main():
     d_status = torch.zeros(N, dtype=torch.uint8, device=dev)
     d_act = torch.zeros(N, dtype=torch.uint8, device=dev)
     last = pl["match"].max(axis=0) + np.uint64(128)
+    d_plan = torch.empty((S, G), dtype=torch.uint8, device=dev)
+    d_next = torch.empty((S, G), dtype=torch.int64, device=dev)
     d_hbytes = torch.empty((S, G, 72), dtype=torch.uint8, device=dev)
     d_hlen = torch.empty((S, G), dtype=torch.uint8, device=dev)
     L = raft_amd.load_library()
@@ -72,6 +75,7 @@ def main():
             ("step_wire", lambda: L.rafthip_step_wire(e._h, d_data.data_ptr(), d_off.data_ptr(), d_grp.data_ptr(), N, None,
                                                      d_status.data_ptr(), None, d_act.data_ptr())),
             ("commit_advance", lambda: e.commit_advance(max_pairs=0)),
+            ("plan_appends", lambda: L.rafthip_plan_appends(e._h, 0, G, 1, d_plan.data_ptr(), d_next.data_ptr(), G)),
             ("emit_heartbeats", lambda: L.rafthip_emit_heartbeats(e._h, 0, G, d_hbytes.data_ptr(), d_hlen.data_ptr())),
             ("check_quorum", lambda: e.check_quorum()),
         ]
@@ -121,6 +125,7 @@ def main():
                           "stage_ms": out, "tick_ms": round(tick, 3), "messages_per_s": N / tick * 1e3,
                           "groups_advanced": int(advanced), "applied": int((d_status == 0).sum().item()),
                           "updated": int(((d_act & 2) != 0).sum().item()),
+                          "appends_planned": int((d_plan != 0).sum().item()),
                           "heartbeats_out": int((d_hlen != 0).sum().item()),
                           "heartbeat_bytes_out": int(d_hlen.sum(dtype=torch.int64).item()),
                           "dense": {"events": dense_events, "stage_ms": out_d, "tick_ms": round(sum(out_d.values()), 3),
