@@ -18,6 +18,7 @@
 //   leader <g> <self> <term_first> <last_index> | follower <g> | setcommitted <g> <c>
 //   appended <g> <last_index> | step <g> <from> <type> <index> <reject 0|1> <ctx 0|1>
 //   maybecommit | checkquorum | hbcommit <g> <id>
+//   plan <g> <send_if_empty 0|1>     -> "plan <g> <id>:<kind>:<next>,..."
 //   heartbeats <g> <term> [ctx-hex]  -> "heartbeat <g> <to> <hex bytes>" per peer, then "heartbeats-done <n>"
 //   progress <max_inflight> <max_bytes> | firstindex <g> <i>
 //   initprogress <g> <default_next> rows=<id>:<state>:<match>:<next>:<pending>:<paused>,...
@@ -255,6 +256,17 @@ int main() {
                 uint64_t c = 0;
                 if (!(rc = trk->HeartbeatCommit(u(1), u(2), &c)))
                     printf("hbcommit %" PRIu64 " %" PRIu64 " %" PRIu64 "\n", u(1), u(2), c);
+            } else if (cmd == "plan") {
+                std::map<uint64_t, tracker::BatchProgressTracker::SendPlan> plan;
+                if (!(rc = trk->PlanAppends(u(1), u(2) != 0, &plan))) {
+                    printf("plan %" PRIu64, u(1));
+                    bool firstp = true;
+                    for (const auto& kv : plan) {
+                        printf("%c%" PRIu64 ":%d:%" PRIu64, firstp ? ' ' : ',', kv.first, kv.second.kind, kv.second.next);
+                        firstp = false;
+                    }
+                    printf("\n");
+                }
             } else if (cmd == "heartbeats") {
                 std::string ctx;
                 if (t.size() > 3)

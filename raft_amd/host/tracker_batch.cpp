@@ -540,6 +540,33 @@ int BatchProgressTracker::BcastHeartbeat(uint64_t group, uint64_t term, const st
     return RAFTHIP_OK;
 }
 
+int BatchProgressTracker::PlanAppends(uint64_t group, bool send_if_empty, std::map<uint64_t, SendPlan>* plan) {
+    if (!plan) return fail(RAFTHIP_EINVAL, "plan is NULL");
+    if (group >= G_) return fail(RAFTHIP_ERANGE, "group %llu outside [0, %llu)", (unsigned long long)group,
+                                 (unsigned long long)G_);
+    if (!progress_) return fail(RAFTHIP_EINVAL, "EnableProgress must come first");
+    int rc = Flush();
+    if (rc) return rc;
+    // RecentActive and the leader's slot as the shadows hold them (the device copies are refreshed lazily; queued
+    // responses set RecentActive on the device too, same bits as the shadow)
+    if (active_dirty_[0] <= active_dirty_[1]) {
+        const uint64_t first = active_dirty_[0], count = active_dirty_[1] - active_dirty_[0] + 1;
+        if ((rc = lib(rafthip_upload_active(e_, first, count, active_.data() + first * mb_)))) return rc;
+        active_dirty_[0] = 1;
+        active_dirty_[1] = 0;
+    }
+    if ((rc = lib(rafthip_upload_self(e_, group, 1, self_.data() + group * mb_)))) return rc;
+    std::vector<uint8_t> kinds(S_);
+    std::vector<uint64_t> next(S_);
+    if ((rc = lib(rafthip_plan_appends(e_, group, 1, send_if_empty ? 1 : 0, kinds.data(), next.data(), 1)))) return rc;
+    plan->clear();
+    const uint64_t* ids = ids_.data() + group * S_;
+    const uint64_t self = get_mask(self_, group);
+    for (uint32_t s = 0; s < S_; ++s)
+        if (((used_[group] >> s) & 1ull) && !((self >> s) & 1ull)) (*plan)[ids[s]] = SendPlan{kinds[s], next[s]};
+    return RAFTHIP_OK;
+}
+
 int BatchProgressTracker::EnableProgress(uint32_t max_inflight, uint64_t max_inflight_bytes) {
     int rc = Flush();
     if (rc) return rc;

@@ -122,6 +122,16 @@ class BatchProgressTracker {
     // context (readOnly.lastPendingRequestCtx, read_only.go:116-121), at most 8 bytes here; empty = nil.
     int BcastHeartbeat(uint64_t group, uint64_t term, const std::string& ctx, std::map<uint64_t, std::string>* msgs);
 
+    // bcastAppend for one led group as a plan (raft.go:689-696): per peer id but the leader's own, what
+    // maybeSendAppend(id, send_if_empty) decides right now (raft.go:600-666) — RAFTHIP_SEND_NONE / _APPEND /
+    // _EMPTY / _SNAPSHOT — and pr.Next (a MsgApp's Index is Next-1, its entries start at Next).  Needs
+    // EnableProgress; steps what is queued first.
+    struct SendPlan {
+        int kind;
+        uint64_t next;
+    };
+    int PlanAppends(uint64_t group, bool send_if_empty, std::map<uint64_t, SendPlan>* plan);
+
     // ---- per-peer replication state: tracker.Progress + tracker.Inflights ----------
     // (tracker/progress.go:30-98, tracker/inflights.go:28-40)
 

@@ -409,7 +409,12 @@ def test_tracker_progress_scenarios():
             return "ev 2 2 %d %d %d %d %d" % (ev_type[st["ev"]], st.get("index", 0), int(bool(st.get("reject"))), flag, aux)
 
         script = list(head)
-        for st in steps:
+        plans = []  # (output line index among the "plan" lines, step, wanted kind)
+        for i, st in enumerate(steps):
+            want = pu.sent_plan(st, sc["src"])
+            if want is not None:  # a send the reference performed from this state: PlanAppends must name it
+                script.append("plan 2 1")
+                plans.append((i, want))
             script += [ev_line(st), "flushprogress", "progressof 2 2"]
         one_batch = len(steps) <= po.STEP_LIMIT and not any(st["ev"] == "appended" for st in steps)
         if one_batch:
@@ -418,6 +423,11 @@ def test_tracker_progress_scenarios():
         out = run_cli("\n".join(script) + "\n")
         assert not [l for l in out if l.startswith("error") or l == "dropped"], out[:5]
         acts = [l for l in out if l.startswith("actions")]
+        plan_lines = [l for l in out if l.startswith("plan ")]
+        assert len(plan_lines) == len(plans)
+        for l, (i, want) in zip(plan_lines, plans):
+            rows = {int(a): (int(b), int(c)) for a, b, c in (t.split(":") for t in l.split()[2].split(","))}
+            assert set(rows) == {2, 3} and rows[2][0] == want, (sc["src"], i, l)  # never to the leader itself (id 1)
         views = [dict(kv.split("=") for kv in l.split()[3:]) for l in out if l.startswith("progressof")]
         assert len(acts) == len(views) == len(steps) + (1 if one_batch else 0)
         for i, st in enumerate(steps):
