@@ -10,7 +10,7 @@
 //   K4  k_commit_wide      9..64 slots: LDS-staged transpose + wave bitonic sort
 //   K3  k_tally_*          VoteResult / QuorumActive / ReadIndex-ack tallies
 //   K5  k_scatter_acks     MsgAppResp stream -> atomicMax on Match
-//       k_scan_counts / k_pack_pairs   ordered compaction of changed commits
+//       k_pack_changed     ordered packing of changed (group, commit) pairs
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -192,47 +192,53 @@ constexpr int kTileGroups = kCommitBlock * 2 * kCH;  // 2048; divides kPlaneAlig
 static_assert(kPlaneAlign % kTileGroups == 0, "a tile must never run off the end of a plane");
 
 // ---------------------------------------------------------------------------
-// Ordered in-block compaction of changed (group, commit) pairs.  Block b owns
-// stage[b*TILE .. (b+1)*TILE) and counts[b]; no atomics, so the packed output
-// is sorted by group and reproducible.  Order inside a tile: chunk, lane, j.
+// Reporting changed (group, commit) pairs, pass 1 of 2 (inside the commit
+// kernels).  A tile is split into spans of one wavefront's groups; per span the
+// wave stores its __ballot words (which lanes changed), per tile the count of
+// changed groups, and per run of kSuperTiles tiles one atomic add of that count.
+// Nothing else: the pairs themselves are written by k_pack_changed, which finds
+// every tile's final offset from those counts and reads the new commit value
+// back from the commit plane — so a pair costs its 16 output bytes plus one
+// 8-byte re-read, instead of a staged copy (16 written + 16 read + 16 written).
+// No atomics order the output: it is sorted by group and reproducible.
 // ---------------------------------------------------------------------------
+constexpr u32 kSuperTiles = 64;
+
+struct Report {
+    u64* __restrict__ bits;    // ballot words: paired tiles 2 per span of 128 groups, lane tiles 1 per span of 64
+    u32* __restrict__ counts;  // [tiles] changed groups per tile
+    u32* __restrict__ super;   // [ceil(tiles / kSuperTiles)] sums of counts; zero before the pass
+};
+
+// Lane-pair tiles (K1/K2): in chunk c lane t of wave w owns groups span*128 + 2t, +1
+// with span = c*NW + w; word 2*span holds the ballot of the even groups, 2*span+1
+// of the odd ones.
 template <int CH, int BLOCK>
-__device__ __forceinline__ void emit_changed(const bool (&ch)[CH][2], const u64 (&grp)[CH][2],
-                                             const u64 (&val)[CH][2], Pair* __restrict__ stage,
-                                             u32* __restrict__ counts) {
+__device__ __forceinline__ void emit_changed(const bool (&ch)[CH][2], Report rep) {
     constexpr int NW = BLOCK / 64;
-    __shared__ u32 wave_tot[CH][NW];
+    __shared__ u32 wave_tot[NW];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const u64 lt = (1ull << lane) - 1ull;
-    u32 before[CH];
+    u32 tot = 0;
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
         const u64 b0 = __ballot(ch[c][0]), b1 = __ballot(ch[c][1]);
-        before[c] = __popcll(b0 & lt) + __popcll(b1 & lt);
-        if (lane == 0) wave_tot[c][wave] = __popcll(b0) + __popcll(b1);
+        tot += __popcll(b0) + __popcll(b1);
+        if (lane == 0) {
+            Vec<u64, 2> w;
+            w.v[0] = b0;
+            w.v[1] = b1;
+            store_vec<u64, 2>(rep.bits + ((u64)blockIdx.x * (CH * NW) + (u64)(c * NW + wave)) * 2, w);
+        }
     }
+    if (lane == 0) wave_tot[wave] = tot;
     __syncthreads();
-    Pair* out = stage + (u64)blockIdx.x * (u64)(BLOCK * 2 * CH);
-    u32 run = 0;
+    if (threadIdx.x == 0) {
+        u32 run = 0;
 #pragma unroll
-    for (int c = 0; c < CH; ++c) {
-        u32 base = run;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) {
-            const u32 t = wave_tot[c][w];
-            base += (w < wave) ? t : 0u;
-            run += t;
-        }
-        u32 pos = base + before[c];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            if (ch[c][j]) {
-                out[pos] = Pair{grp[c][j], val[c][j]};
-                ++pos;
-            }
-        }
+        for (int w = 0; w < NW; ++w) run += wave_tot[w];
+        rep.counts[blockIdx.x] = run;
+        if (run) atomicAdd(rep.super + blockIdx.x / kSuperTiles, run);
     }
-    if (threadIdx.x == 0) counts[blockIdx.x] = run;
 }
 
 // What a commit pass does with a group's quorum commit index (mci):
@@ -255,11 +261,9 @@ struct LogBounds {  // per-group planes used by kAdvance only
 // Store the tile's results; report changed / advanced pairs as MODE says.
 template <int CH, int BLOCK, int MODE>
 __device__ __forceinline__ void finish_tile(const Vec<u64, 2> (&res)[CH], u64 base, u64 G,
-                                            u64* __restrict__ commit, LogBounds lb,
-                                            Pair* __restrict__ stage, u32* __restrict__ counts) {
+                                            u64* __restrict__ commit, LogBounds lb, Report rep) {
     if constexpr (MODE != kStore) {
         bool ch[CH][2];
-        u64 grp[CH][2], val[CH][2];
         Vec<u64, 2> nxt[CH];
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
@@ -273,20 +277,18 @@ __device__ __forceinline__ void finish_tile(const Vec<u64, 2> (&res)[CH], u64 ba
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const u64 r = res[c].v[j];
-                grp[c][j] = g0 + j;
-                val[c][j] = r;
                 if constexpr (MODE == kAdvance) {
-                    ch[c][j] = (grp[c][j] < G) && (r > old.v[j]) && (r >= ts.v[j]) && (r <= li.v[j]);
+                    ch[c][j] = (g0 + j < G) && (r > old.v[j]) && (r >= ts.v[j]) && (r <= li.v[j]);
                     nxt[c].v[j] = ch[c][j] ? r : old.v[j];
                 } else {
-                    ch[c][j] = (grp[c][j] < G) && (old.v[j] != r);
+                    ch[c][j] = (g0 + j < G) && (old.v[j] != r);
                     nxt[c].v[j] = r;
                 }
             }
         }
 #pragma unroll
         for (int c = 0; c < CH; ++c) store_stream<u64, 2>(commit + base + (u64)c * BLOCK * 2, nxt[c]);
-        emit_changed<CH, BLOCK>(ch, grp, val, stage, counts);
+        emit_changed<CH, BLOCK>(ch, rep);
     } else {
 #pragma unroll
         for (int c = 0; c < CH; ++c) store_stream<u64, 2>(commit + base + (u64)c * BLOCK * 2, res[c]);
@@ -300,8 +302,7 @@ template <int V, int MODE>
 __global__ __launch_bounds__(kCommitBlock) void k_commit_uniform(const u64* __restrict__ match,
                                                                  u64 stride, u64 G,
                                                                  u64* __restrict__ commit, LogBounds lb,
-                                                                 Pair* __restrict__ stage,
-                                                                 u32* __restrict__ counts) {
+                                                                 Report rep) {
     const u64 base = (u64)blockIdx.x * kTileGroups + threadIdx.x * 2;
     Vec<u64, 2> in[kCH][V];
 #pragma unroll
@@ -319,7 +320,7 @@ __global__ __launch_bounds__(kCommitBlock) void k_commit_uniform(const u64* __re
             for (int s = 0; s < V; ++s) a[s] = in[c][s].v[j];
             res[c].v[j] = committed_fixed<V>(a);
         }
-    finish_tile<kCH, kCommitBlock, MODE>(res, base, G, commit, lb, stage, counts);
+    finish_tile<kCH, kCommitBlock, MODE>(res, base, G, commit, lb, rep);
 }
 
 // ---------------------------------------------------------------------------
@@ -335,8 +336,7 @@ __global__ __launch_bounds__(BLOCK) void k_commit_masked(const u64* __restrict__
                                                          const MaskT* __restrict__ in_mask,
                                                          const MaskT* __restrict__ out_mask,
                                                          u32 uniform_voters, u64* __restrict__ commit,
-                                                         LogBounds lb, Pair* __restrict__ stage,
-                                                         u32* __restrict__ counts) {
+                                                         LogBounds lb, Report rep) {
     const u64 base = (u64)blockIdx.x * (BLOCK * 2 * CH) + threadIdx.x * 2;
     Vec<u64, 2> in[CH][S];
     Vec<MaskT, 2> m0[CH], m1[CH];
@@ -374,7 +374,7 @@ __global__ __launch_bounds__(BLOCK) void k_commit_masked(const u64* __restrict__
             }
             res[c].v[j] = r;
         }
-    finish_tile<CH, BLOCK, MODE>(res, base, G, commit, lb, stage, counts);
+    finish_tile<CH, BLOCK, MODE>(res, base, G, commit, lb, rep);
 }
 constexpr int kMidBlock = 256;                 // tile shape of K2 at 9..16 slots
 constexpr int kMidTileGroups = kMidBlock * 2;  // 512; divides kPlaneAlign
@@ -383,8 +383,7 @@ constexpr int kMidTileGroups = kMidBlock * 2;  // 512; divides kPlaneAlign
 // store / diff / term-guard as MODE says, with the same ordered in-block
 // compaction of reported pairs as emit_changed.
 template <int MODE>
-__device__ __forceinline__ void finish_lane(u64 res, u64 g, u64 G, u64* __restrict__ commit, LogBounds lb,
-                                            Pair* __restrict__ stage, u32* __restrict__ counts) {
+__device__ __forceinline__ void finish_lane(u64 res, u64 g, u64 G, u64* __restrict__ commit, LogBounds lb, Report rep) {
     if constexpr (MODE != kStore) {
         __shared__ u32 wave_tot[kBlock / 64];
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -398,17 +397,18 @@ __device__ __forceinline__ void finish_lane(u64 res, u64 g, u64 G, u64* __restri
             commit[g] = res;
         }
         const u64 b = __ballot(chg);
-        if (lane == 0) wave_tot[wave] = __popcll(b);
-        __syncthreads();
-        u32 pos = __popcll(b & ((1ull << lane) - 1ull)), all = 0;
-#pragma unroll
-        for (int w = 0; w < kBlock / 64; ++w) {
-            const u32 t = wave_tot[w];
-            pos += (w < wave) ? t : 0u;
-            all += t;
+        if (lane == 0) {
+            rep.bits[(u64)blockIdx.x * (kBlock / 64) + wave] = b;  // one span of 64 groups per wave
+            wave_tot[wave] = __popcll(b);
         }
-        if (chg) stage[(u64)blockIdx.x * kBlock + pos] = Pair{g, res};
-        if (threadIdx.x == 0) counts[blockIdx.x] = all;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            u32 all = 0;
+#pragma unroll
+            for (int w = 0; w < kBlock / 64; ++w) all += wave_tot[w];
+            rep.counts[blockIdx.x] = all;
+            if (all) atomicAdd(rep.super + blockIdx.x / kSuperTiles, all);
+        }
     } else {
         commit[g] = res;
     }
@@ -493,8 +493,7 @@ __global__ __launch_bounds__(kBlock, (N > 32 ? 3 : 1)) void k_commit_regs(const 
                                                         int S, const MaskT* __restrict__ in_mask,
                                                         const MaskT* __restrict__ out_mask,
                                                         int uniform_voters, u64* __restrict__ commit,
-                                                        LogBounds lb, Pair* __restrict__ stage,
-                                                        u32* __restrict__ counts) {
+                                                        LogBounds lb, Report rep) {
     const u64 g = (u64)blockIdx.x * kBlock + threadIdx.x;  // < stride (stride is a multiple of 4096)
     u64 m0, m1;
     if (in_mask) {
@@ -529,7 +528,7 @@ __global__ __launch_bounds__(kBlock, (N > 32 ? 3 : 1)) void k_commit_regs(const 
     } else {
         res = regs_half<N, true>(match, stride, S, m0);
     }
-    finish_lane<MODE>(res, g, G, commit, lb, stage, counts);
+    finish_lane<MODE>(res, g, G, commit, lb, rep);
 }
 
 // ---------------------------------------------------------------------------
@@ -600,8 +599,7 @@ __global__ __launch_bounds__(kBlock) void k_commit_wide(const u64* __restrict__ 
                                                         u64 G, int S, const MaskT* __restrict__ in_mask,
                                                         const MaskT* __restrict__ out_mask,
                                                         int uniform_voters, u64* __restrict__ commit,
-                                                        LogBounds lb, Pair* __restrict__ stage,
-                                                        u32* __restrict__ counts) {
+                                                        LogBounds lb, Report rep) {
     extern __shared__ u64 lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     u64* tile = lds + (size_t)wave * (size_t)S * kTileStride;
@@ -644,45 +642,83 @@ __global__ __launch_bounds__(kBlock) void k_commit_wide(const u64* __restrict__ 
                        (u64)(u32)__shfl((int)(u32)r, owner_seg, 64);
         if (lane / GPI == it) res = rr;
     }
-    finish_lane<MODE>(res, g, G, commit, lb, stage, counts);
+    finish_lane<MODE>(res, g, G, commit, lb, rep);
 }
 
 // ---------------------------------------------------------------------------
-// Changed-pair packing: exclusive scan of per-block counts, then copy every
-// block's ordered run to its offset.
+// Reporting changed pairs, pass 2 of 2: one workgroup per tile of the commit
+// pass.  A tile without a changed group leaves at once.  The others find their
+// offset in the output — the super counts before their run of kSuperTiles tiles
+// plus the tile counts before them inside it, one wave reduction — and each wave
+// writes the pairs of its spans in group order: (group_base + g, commit[g]) for
+// every set ballot bit, positions by popcount prefix.  The last tile also stores
+// the total.  Pairs beyond max_pairs are counted, not written.
+//   PAIRED  spans of 128 groups, two ballot words (even / odd groups)  — K1, K2
+//   else    spans of 64 groups, one ballot word                        — K4r, K4
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_scan_counts(const u32* __restrict__ counts, u32 nblocks,
-                                                      u64* __restrict__ offsets) {
-    __shared__ u64 part[1024];
-    const u32 t = threadIdx.x;
-    const u32 per = (nblocks + 1023u) / 1024u;
-    const u32 lo = t * per, hi = (lo + per < nblocks) ? lo + per : nblocks;
-    u64 sum = 0;
-    for (u32 i = lo; i < hi; ++i) sum += counts[i];
-    part[t] = sum;
+constexpr u32 kMaxSpans = 16;  // 2048-group tile of K1/K2
+
+template <bool PAIRED>
+__global__ __launch_bounds__(kBlock) void k_pack_changed(const u64* __restrict__ bits,
+                                                         const u32* __restrict__ counts,
+                                                         const u32* __restrict__ super, u32 ntiles,
+                                                         u32 spans, const u64* __restrict__ commit,
+                                                         u64 group_base, Pair* __restrict__ out,
+                                                         u64 max_pairs, u64* __restrict__ total) {
+    const u32 tile = blockIdx.x;
+    const u32 n = counts[tile];
+    const bool last = tile == ntiles - 1;
+    if (n == 0 && !last) return;  // uniform over the workgroup
+    __shared__ u64 s_off;
+    __shared__ u32 s_cnt[kMaxSpans];
+    const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr u32 W = PAIRED ? 2 : 1;
+    const u64* tb = bits + (u64)tile * spans * W;
+    if (wave == 0) {
+        const u32 sb = tile / kSuperTiles;
+        u64 sum = 0;
+        for (u32 i = lane; i < sb; i += 64) sum += super[i];
+        for (u32 i = sb * kSuperTiles + lane; i < tile; i += 64) sum += counts[i];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const u32 lo = (u32)__shfl_xor((int)(u32)sum, d, 64), hi = (u32)__shfl_xor((int)(u32)(sum >> 32), d, 64);
+            sum += ((u64)hi << 32) | lo;
+        }
+        if (lane == 0) {
+            s_off = sum;
+            if (last) *total = sum + n;
+        }
+    } else if (wave == 1 && lane < spans) {
+        u32 c = __popcll(tb[lane * W]);
+        if (PAIRED) c += __popcll(tb[lane * W + 1]);
+        s_cnt[lane] = c;
+    }
+    if (n == 0) return;
     __syncthreads();
-    for (u32 d = 1; d < 1024; d <<= 1) {  // Hillis-Steele inclusive scan
-        const u64 add = (t >= d) ? part[t - d] : 0;
-        __syncthreads();
-        part[t] += add;
-        __syncthreads();
+    const u64 lt = (1ull << lane) - 1ull;
+    for (u32 s = wave; s < spans; s += kBlock / 64) {
+        u64 pos = s_off;
+        for (u32 k = 0; k < s; ++k) pos += s_cnt[k];
+        if (PAIRED) {
+            const u64 b0 = tb[2 * s], b1 = tb[2 * s + 1];
+            const u64 g = ((u64)tile * spans + s) * 128 + 2 * lane;
+            pos += __popcll(b0 & lt) + __popcll(b1 & lt);
+            const bool c0 = (b0 >> lane) & 1ull, c1 = (b1 >> lane) & 1ull;
+            if (c0 | c1) {
+                const Vec<u64, 2> v = load_vec<u64, 2>(commit + g);
+                if (c0) {
+                    if (pos < max_pairs) out[pos] = Pair{group_base + g, v.v[0]};
+                    ++pos;
+                }
+                if (c1 && pos < max_pairs) out[pos] = Pair{group_base + g + 1, v.v[1]};
+            }
+        } else {
+            const u64 b = tb[s];
+            const u64 g = ((u64)tile * spans + s) * 64 + lane;
+            pos += __popcll(b & lt);
+            if (((b >> lane) & 1ull) && pos < max_pairs) out[pos] = Pair{group_base + g, commit[g]};
+        }
     }
-    u64 run = part[t] - sum;
-    for (u32 i = lo; i < hi; ++i) {
-        offsets[i] = run;
-        run += counts[i];
-    }
-    if (t == 1023) offsets[nblocks] = part[1023];
-}
-
-__global__ __launch_bounds__(kBlock) void k_pack_pairs(const Pair* __restrict__ stage,
-                                                       const u32* __restrict__ counts,
-                                                       const u64* __restrict__ offsets, u32 block_groups,
-                                                       Pair* __restrict__ packed) {
-    const u32 n = counts[blockIdx.x];
-    const Pair* src = stage + (u64)blockIdx.x * block_groups;
-    Pair* dst = packed + offsets[blockIdx.x];
-    for (u32 i = threadIdx.x; i < n; i += kBlock) dst[i] = src[i];
 }
 
 // ---------------------------------------------------------------------------

@@ -110,12 +110,11 @@ struct rafthip_engine {
     uint8_t* ack_result = nullptr;
     uint8_t* in_term = nullptr;
 
-    // changed-pair compaction
-    Pair* stage = nullptr;
-    Pair* packed = nullptr;
-    u32* counts = nullptr;
-    u64* offsets = nullptr;
-    u32 counts_cap = 0;
+    // changed-pair reporting (kernels.h: Report, k_pack_changed)
+    u64* rep_bits = nullptr;    // ballot words, one bit per group of [0, stride)
+    u32* rep_counts = nullptr;  // [stride / kBlock] per-tile counts (sized for the smallest tile)
+    u32* rep_super = nullptr;   // [ceil(tiles / kSuperTiles)] + the total as the u64 behind them
+    Pair* packed = nullptr;     // landing buffer when the caller's dst is pageable host memory
 
     // scatter
     Ack* ack_buf = nullptr;  // staging for host-resident ack / msg records (both 16 B)
@@ -203,8 +202,9 @@ bool small_commit_path(const rafthip_engine* e) {
 bool mid_commit_path(const rafthip_engine* e) { return !small_commit_path(e) && e->S <= 16 && !e->wide_bitonic; }
 
 template <int MODE>
-int launch_commit(rafthip_engine* e, u32* block_groups) {
-    constexpr bool CHANGED = MODE != kStore;  // needs the stage / counts buffers
+int launch_commit(rafthip_engine* e, u32* block_groups, Report rep = Report{nullptr, nullptr, nullptr},
+                  u32 tiles_cap = 0) {
+    constexpr bool CHANGED = MODE != kStore;  // needs the report buffers
     const u64 G = e->G;
     hipStream_t st = e->stream;
     const LogBounds lb{e->term_first, e->term_last};
@@ -220,13 +220,13 @@ int launch_commit(rafthip_engine* e, u32* block_groups) {
         // it whatever S is (e.g. 7 voters + 2 learner rows).
         const u32 blocks = (u32)((G + kTileGroups - 1) / kTileGroups);
         *block_groups = kTileGroups;
-        if (CHANGED && blocks > e->counts_cap) return fail(RAFTHIP_EINVAL, "internal: counts capacity");
+        if (CHANGED && blocks > tiles_cap) return fail(RAFTHIP_EINVAL, "internal: report capacity");
         if (uni) {
             switch (e->uniform_voters) {
 #define RAFTHIP_CASE_U(V)                                                                          \
     case V:                                                                                        \
         hipLaunchKernelGGL((k_commit_uniform<V, MODE>), dim3(blocks), dim3(kCommitBlock), 0, st,      \
-                           e->match, e->stride, G, e->commit, lb, e->stage, e->counts);            \
+                           e->match, e->stride, G, e->commit, lb, rep);                        \
         break;
                 RAFTHIP_CASE_U(1) RAFTHIP_CASE_U(2) RAFTHIP_CASE_U(3) RAFTHIP_CASE_U(4)
                 RAFTHIP_CASE_U(5) RAFTHIP_CASE_U(6) RAFTHIP_CASE_U(7) RAFTHIP_CASE_U(8)
@@ -241,7 +241,7 @@ int launch_commit(rafthip_engine* e, u32* block_groups) {
     case SS:                                                                                       \
         hipLaunchKernelGGL((k_commit_masked<SS, uint8_t, MODE, kCommitBlock, kCH>), dim3(blocks),     \
                            dim3(kCommitBlock), 0, st, e->match, e->stride, G, m0, m1, 0u, e->commit,  \
-                           lb, e->stage, e->counts);                                               \
+                           lb, rep);                                                               \
         break;
                 RAFTHIP_CASE_M(1) RAFTHIP_CASE_M(2) RAFTHIP_CASE_M(3) RAFTHIP_CASE_M(4)
                 RAFTHIP_CASE_M(5) RAFTHIP_CASE_M(6) RAFTHIP_CASE_M(7) RAFTHIP_CASE_M(8)
@@ -252,7 +252,7 @@ int launch_commit(rafthip_engine* e, u32* block_groups) {
     } else if (mid_commit_path(e)) {
         const u32 blocks = (u32)((G + kMidTileGroups - 1) / kMidTileGroups);
         *block_groups = kMidTileGroups;
-        if (CHANGED && blocks > e->counts_cap) return fail(RAFTHIP_EINVAL, "internal: counts capacity");
+        if (CHANGED && blocks > tiles_cap) return fail(RAFTHIP_EINVAL, "internal: report capacity");
         const uint16_t* m0 = uni ? nullptr : static_cast<const uint16_t*>(e->in_mask);
         const uint16_t* m1 = uni ? nullptr : static_cast<const uint16_t*>(e->out_mask);
         switch (e->S) {
@@ -260,7 +260,7 @@ int launch_commit(rafthip_engine* e, u32* block_groups) {
     case SS:                                                                                       \
         hipLaunchKernelGGL((k_commit_masked<SS, uint16_t, MODE, kMidBlock, 1>), dim3(blocks),      \
                            dim3(kMidBlock), 0, st, e->match, e->stride, G, m0, m1,                 \
-                           uni ? e->uniform_voters : 0u, e->commit, lb, e->stage, e->counts);      \
+                           uni ? e->uniform_voters : 0u, e->commit, lb, rep);                      \
         break;
             RAFTHIP_CASE_MM(9) RAFTHIP_CASE_MM(10) RAFTHIP_CASE_MM(11) RAFTHIP_CASE_MM(12)
             RAFTHIP_CASE_MM(13) RAFTHIP_CASE_MM(14) RAFTHIP_CASE_MM(15) RAFTHIP_CASE_MM(16)
@@ -270,7 +270,7 @@ int launch_commit(rafthip_engine* e, u32* block_groups) {
     } else {
         const u32 blocks = (u32)((G + kBlock - 1) / kBlock);
         *block_groups = kBlock;
-        if (CHANGED && blocks > e->counts_cap) return fail(RAFTHIP_EINVAL, "internal: counts capacity");
+        if (CHANGED && blocks > tiles_cap) return fail(RAFTHIP_EINVAL, "internal: report capacity");
         const int uv = uni ? (int)e->uniform_voters : 0;
         if (e->wide_bitonic) {
             const size_t lds = (size_t)(kBlock / 64) * e->S * kTileStride * sizeof(u64);
@@ -279,7 +279,7 @@ int launch_commit(rafthip_engine* e, u32* block_groups) {
                        e->match, e->stride, G, (int)e->S,                                          \
                        uni ? nullptr : static_cast<const MT*>(e->in_mask),                         \
                        uni ? nullptr : static_cast<const MT*>(e->out_mask), uv, e->commit, lb,     \
-                       e->stage, e->counts)
+                       rep)
             if (e->S <= 16) {
                 RAFTHIP_WIDE(16, uint16_t);
             } else if (e->S <= 32) {
@@ -294,7 +294,7 @@ int launch_commit(rafthip_engine* e, u32* block_groups) {
                        e->match, e->stride, G, (int)e->S,                                          \
                        uni ? nullptr : static_cast<const MT*>(e->in_mask),                         \
                        uni ? nullptr : static_cast<const MT*>(e->out_mask), uv, e->commit, lb,     \
-                       e->stage, e->counts)
+                       rep)
             if (e->S <= 24) {
                 RAFTHIP_REGS(24, uint32_t);
             } else if (e->S <= 32) {
@@ -313,16 +313,58 @@ int launch_commit(rafthip_engine* e, u32* block_groups) {
     return RAFTHIP_OK;
 }
 
-int ensure_changed_buffers(rafthip_engine* e) {
+// The scratch of one reporting pass (any memory the device can address; the engine's
+// own buffers, or the static array of rafthip_commit_changed_static).
+struct ReportBufs {
+    u64* bits;
+    u32* counts;
+    u32* super;  // followed by the u64 total
+    u64* total;
+    u32 tiles_cap;
+};
+
+u32 super_words(u32 tiles) { return (tiles + kSuperTiles - 1) / kSuperTiles; }
+// bytes of `super` + total for a plane of `stride` groups (smallest tile = kBlock), total 8-byte aligned
+size_t super_bytes(u64 stride) { return round_up((size_t)super_words((u32)(stride / kBlock)) * sizeof(u32), 8) + 8; }
+
+int ensure_report_buffers(rafthip_engine* e, ReportBufs* rb) {
     // Sized for either tiling (a conf change may move an engine between them):
-    // tiles partition [0, stride), and kBlock is the smaller tile.
-    const u32 blocks = (u32)(e->stride / kBlock);
+    // tiles partition [0, stride), and kBlock is the smallest tile.
+    const u32 tiles = (u32)(e->stride / kBlock);
     int rc;
-    if ((rc = ensure(e, e->stage, (size_t)e->stride * sizeof(Pair), false))) return rc;
-    if ((rc = ensure(e, e->packed, (size_t)e->stride * sizeof(Pair), false))) return rc;
-    if ((rc = ensure(e, e->counts, (size_t)blocks * sizeof(u32)))) return rc;
-    if ((rc = ensure(e, e->offsets, ((size_t)blocks + 1) * sizeof(u64)))) return rc;
-    e->counts_cap = blocks;
+    if ((rc = ensure(e, e->rep_bits, (size_t)e->stride / 8, false))) return rc;
+    if ((rc = ensure(e, e->rep_counts, (size_t)tiles * sizeof(u32), false))) return rc;
+    if ((rc = ensure(e, e->rep_super, super_bytes(e->stride), false))) return rc;
+    rb->bits = e->rep_bits;
+    rb->counts = e->rep_counts;
+    rb->super = e->rep_super;
+    rb->total = reinterpret_cast<u64*>(reinterpret_cast<char*>(e->rep_super) + super_bytes(e->stride) - 8);
+    rb->tiles_cap = tiles;
+    return RAFTHIP_OK;
+}
+
+// One reporting pass, asynchronous on the engine's stream: zero the super counts,
+// run the commit kernel in MODE (ballot words + counts), pack the pairs of the
+// changed / advanced groups to d_out (device-addressable, room for max_pairs) with
+// group ids rebased by group_base, leave the total in *rb.total.  Allocates nothing.
+template <int MODE>
+int report_pass(rafthip_engine* e, const ReportBufs& rb, u64 group_base, Pair* d_out, u64 max_pairs) {
+    static_assert(MODE != kStore, "a reporting mode");
+    HIP_TRY(hipMemsetAsync(rb.super, 0, (size_t)super_words(rb.tiles_cap) * sizeof(u32), e->stream));
+    u32 bg = 0;
+    int rc = launch_commit<MODE>(e, &bg, Report{rb.bits, rb.counts, rb.super}, rb.tiles_cap);
+    if (rc) return rc;
+    const u32 tiles = (u32)((e->G + bg - 1) / bg);
+    const bool paired = bg != (u32)kBlock;  // K1 / K2 tiles; the one-group-per-lane kernels use kBlock
+    const u32 spans = paired ? bg / 128 : bg / 64;
+    if (paired) {
+        hipLaunchKernelGGL(k_pack_changed<true>, dim3(tiles), dim3(kBlock), 0, e->stream, rb.bits, rb.counts, rb.super,
+                           tiles, spans, e->commit, group_base, d_out, max_pairs, rb.total);
+    } else {
+        hipLaunchKernelGGL(k_pack_changed<false>, dim3(tiles), dim3(kBlock), 0, e->stream, rb.bits, rb.counts, rb.super,
+                           tiles, spans, e->commit, group_base, d_out, max_pairs, rb.total);
+    }
+    HIP_TRY(hipGetLastError());
     return RAFTHIP_OK;
 }
 
@@ -460,36 +502,51 @@ static int stage_records(rafthip_engine* e, const void* recs, uint64_t n, const 
     return RAFTHIP_OK;
 }
 
-// Commit pass that reports pairs (MODE kChanged / kAdvance): launch, scan the
-// per-tile counts, pack the ordered runs, hand back the total and the pairs.
+// dst as memory the pack kernel can write itself: device memory, or page-locked host
+// memory through its device alias.  NULL for pageable host memory.
+Pair* device_addressable(void* dst) {
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, dst) == hipSuccess) {
+        if (attr.type == hipMemoryTypeDevice) return static_cast<Pair*>(dst);
+        if (attr.type == hipMemoryTypeHost && attr.devicePointer) return static_cast<Pair*>(attr.devicePointer);
+    }
+    (void)hipGetLastError();  // plain host memory reports an error on some runtimes
+    return nullptr;
+}
+
+// Commit pass that reports pairs (MODE kChanged / kAdvance): the reporting pass,
+// then the total and — for a pageable dst — the pairs come back.
 template <int MODE>
 static int commit_report(rafthip_engine* e, rafthip_commit_pair* dst, uint64_t max_pairs, uint64_t* n_out) {
     if (!e || !n_out) return fail(RAFTHIP_EINVAL, "engine/count pointer is NULL");
     if (max_pairs > 0 && !dst) return fail(RAFTHIP_EINVAL, "dst is NULL with max_pairs > 0");
     DeviceGuard guard(e->device);
-    int rc = ensure_changed_buffers(e);
+    ReportBufs rb;
+    int rc = ensure_report_buffers(e, &rb);
     if (rc) return rc;
     if (MODE == kAdvance) {
         if ((rc = ensure(e, e->term_first, (size_t)e->stride * sizeof(u64)))) return rc;
         if ((rc = ensure(e, e->term_last, (size_t)e->stride * sizeof(u64)))) return rc;
     }
-    u32 bg = 0;
-    if ((rc = launch_commit<MODE>(e, &bg))) return rc;
-    const u32 blocks = (u32)((e->G + bg - 1) / bg);
-    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, e->stream, e->counts, blocks, e->offsets);
-    hipLaunchKernelGGL(k_pack_pairs, dim3(blocks), dim3(kBlock), 0, e->stream, e->stage, e->counts,
-                       e->offsets, bg, e->packed);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(e->h_scalar + 1, e->offsets + blocks, sizeof(u64), hipMemcpyDeviceToHost, e->stream));
+    Pair* d_out = max_pairs ? device_addressable(dst) : nullptr;
+    const bool landing = max_pairs && !d_out;
+    u64 cap = max_pairs;
+    if (landing) {  // pageable host memory: pack on the device, copy what fits
+        if ((rc = ensure(e, e->packed, (size_t)e->stride * sizeof(Pair), false))) return rc;
+        d_out = e->packed;
+        cap = max_pairs < e->G ? max_pairs : e->G;
+    }
+    if ((rc = report_pass<MODE>(e, rb, 0, d_out, cap))) return rc;
+    HIP_TRY(hipMemcpyAsync(e->h_scalar + 1, rb.total, sizeof(u64), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     const u64 total = e->h_scalar[1];
     *n_out = total;
     const u64 ncopy = total < max_pairs ? total : max_pairs;
-    if (ncopy) {
-        HIP_TRY(hipMemcpyAsync(dst, e->packed, ncopy * sizeof(Pair), hipMemcpyDefault, e->stream));
+    if (landing && ncopy) {
+        HIP_TRY(hipMemcpyAsync(dst, e->packed, ncopy * sizeof(Pair), hipMemcpyDeviceToHost, e->stream));
         HIP_TRY(hipStreamSynchronize(e->stream));
-        e->stats.bytes_downloaded += ncopy * sizeof(Pair);
     }
+    e->stats.bytes_downloaded += ncopy * sizeof(Pair);
     if (MODE == kAdvance) {
         e->stats.advanced_reported += total;
     } else {
@@ -644,7 +701,7 @@ int rafthip_destroy(rafthip_engine* e) {
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     void* bufs[] = {e->in_mask, e->out_mask,   e->learner_mask, e->match,    e->commit, e->votes,
                     e->active,  e->acks,       e->vote_result,  e->granted,  e->rejected, e->qactive,
-                    e->ack_result, e->stage,   e->packed,       e->counts,   e->offsets,  e->ack_buf,
+                    e->ack_result, e->rep_bits, e->packed,      e->rep_counts, e->rep_super, e->ack_buf,
                     e->d_rejected, e->self_mask, e->term_first, e->term_last, e->hb_commit, e->in_term,
                     e->wire_hdr, e->d_wire_counts, e->pp.rec, e->pp.ring_index, e->pp.ring_bytes,
                     e->first_index, e->vote_first};
