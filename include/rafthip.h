@@ -488,6 +488,23 @@ int rafthip_commit_changed(rafthip_engine *e, rafthip_commit_pair *dst, uint64_t
 int rafthip_commit_advance(rafthip_engine *e, rafthip_commit_pair *dst, uint64_t max_pairs,
                            uint64_t *n_advanced);
 int rafthip_read_commit(rafthip_engine *e, uint64_t first, uint64_t count, uint64_t *dst);
+
+/* rafthip_commit_changed for callers that cannot allocate device memory: code
+ * under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.
+ * No counterpart in the reference.  Same pass and same result as
+ * rafthip_commit_changed, but its scratch (ballot words, per-tile counts, the
+ * total) lives in a static device array of the library — 2.3 MiB per GPU, held
+ * until the process ends — and the call makes no hipMalloc / hipFree or any
+ * other allocating call.  Limits: engines of at most RAFTHIP_STATIC_MAX_GROUPS
+ * groups (after rounding up to 4096; larger: RAFTHIP_EINVAL); dst must be
+ * device memory or page-locked host memory (rafthip_host_alloc), written by the
+ * kernel itself; a config must have been set (rafthip_set_uniform_config with
+ * voters >= 1, or rafthip_upload_config).  Every call on one GPU shares that
+ * GPU's array: calls that overlap on one GPU (two engines, two threads) race;
+ * serialise them.  Waits for the GPU like rafthip_commit_changed. */
+#define RAFTHIP_STATIC_MAX_GROUPS (1ull << 24)
+int rafthip_commit_changed_static(rafthip_engine *e, rafthip_commit_pair *dst, uint64_t max_pairs,
+                                  uint64_t *n_changed);
 /* bcastHeartbeat as serialized bytes — raft.go:698-716 (bcastHeartbeat,
  * bcastHeartbeatWithCtx), sendHeartbeat raft.go:669-685, r.send raft.go:502-533:
  * for every Progress row (slot s, group first+g) whose id is not 0, except the

@@ -44,7 +44,7 @@ SYMBOLS = [
     "rafthip_read_inflights", "rafthip_upload_first_index", "rafthip_step_progress", "rafthip_step_wire",
     "rafthip_merge_acks", "rafthip_host_alloc", "rafthip_host_free",
     "rafthip_record_votes", "rafthip_read_votes", "rafthip_step_dense", "rafthip_upload_campaign",
-    "rafthip_emit_heartbeats", "rafthip_plan_appends",
+    "rafthip_emit_heartbeats", "rafthip_plan_appends", "rafthip_commit_changed_static",
 ]
 MSG_VOTE_RESP, MSG_PRE_VOTE_RESP = 6, 18
 
@@ -138,6 +138,7 @@ def load_library():
         "rafthip_scatter_acks": (i32, [vp, vp, u64]),
         "rafthip_commit": (i32, [vp]),
         "rafthip_commit_changed": (i32, [vp, vp, u64, C.POINTER(u64)]),
+        "rafthip_commit_changed_static": (i32, [vp, vp, u64, C.POINTER(u64)]),
         "rafthip_read_commit": (i32, [vp, u64, u64, vp]),
         "rafthip_tally_votes": (i32, [vp]),
         "rafthip_read_vote_result": (i32, [vp, u64, u64, vp, vp, vp]),
@@ -353,6 +354,13 @@ class Engine:
         _check(self._L.rafthip_commit_changed(self._h, _ptr(out) if max_pairs else None, max_pairs,
                                               C.byref(n)))
         return out[:min(n.value, max_pairs)], n.value
+
+    def commit_changed_static(self, dst, max_pairs):
+        """rafthip_commit_changed_static: pairs land at `dst` (device or page-locked host address, room
+        for max_pairs pairs); allocates nothing.  Returns the total number of changed groups."""
+        n = C.c_uint64()
+        _check(self._L.rafthip_commit_changed_static(self._h, _ptr(dst) if max_pairs else None, max_pairs, C.byref(n)))
+        return n.value
 
     def commit_report_into(self, dst, max_pairs, advance=False):
         """commit_changed / commit_advance with the pairs landing at `dst` (host or device

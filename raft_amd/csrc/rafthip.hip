@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <mutex>
 #include <new>
 
 #include "kernels.h"
@@ -57,6 +58,39 @@ constexpr u64 kMaxRecordsPerLaunch = 1ull << 30;  // scatter / ingest records pe
 
 int mask_bytes_for(u32 S) { return S <= 8 ? 1 : S <= 16 ? 2 : S <= 32 ? 4 : 8; }
 
+}  // namespace
+
+// ---- scratch of the allocation-free entry point (rafthip_commit_changed_static) ----
+// One copy per GPU the library runs on, held until the process ends.  Layout:
+// ballot words, per-tile counts, super counts + total, for planes of up to
+// kStaticMaxGroups groups.  Host code never passes the array's name to a kernel
+// (that name is a host-side stand-in, not a device address): static_scratch()
+// resolves the address once per device and every use goes through it.
+constexpr u64 kStaticMaxGroups = 1ull << 24;
+constexpr size_t kStaticBitsBytes = kStaticMaxGroups / 8;
+constexpr size_t kStaticCountsBytes = kStaticMaxGroups / kBlock * sizeof(u32);
+constexpr size_t kStaticSuperBytes = (kStaticMaxGroups / kBlock + kSuperTiles - 1) / kSuperTiles * sizeof(u32) + 8;
+constexpr size_t kStaticScratchBytes = kStaticBitsBytes + kStaticCountsBytes + ((kStaticSuperBytes + 255) & ~(size_t)255);
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mu;
+void* g_scratch_ptr[kMaxDevices] = {};
+
+// Address of this device's copy of `scratch` (device must be current).  Resolved
+// on the first rafthip_create on a device; later calls only read the table.
+int static_scratch(int device, void** out) {
+    if (device < 0 || device >= kMaxDevices) return fail(RAFTHIP_EINVAL, "device %d outside the scratch table", device);
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!g_scratch_ptr[device]) {
+        void* ptr = nullptr;
+        HIP_TRY(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+        g_scratch_ptr[device] = ptr;
+    }
+    *out = g_scratch_ptr[device];
+    return RAFTHIP_OK;
+}
 }  // namespace
 
 // Roles of the engine's staging buffers (an entry point uses each role for one thing at a time).
@@ -673,6 +707,8 @@ int rafthip_create(const rafthip_config* cfg, rafthip_engine** out) {
             }
             e->own_stream = true;
         }
+        void* scratch_ptr = nullptr;  // set-up of rafthip_commit_changed_static: once per device
+        if ((rc = static_scratch(e->device, &scratch_ptr))) break;
         if ((rc = ensure(e, e->match, (size_t)e->S * e->stride * sizeof(u64)))) break;
         if ((rc = ensure(e, e->commit, (size_t)e->stride * sizeof(u64)))) break;
         if ((rc = ensure(e, e->d_rejected, 4 * sizeof(u64)))) break;
@@ -1687,6 +1723,42 @@ int rafthip_commit_advance(rafthip_engine* e, rafthip_commit_pair* dst, uint64_t
     return commit_report<kAdvance>(e, dst, max_pairs, n_advanced);
 }
 
+int rafthip_commit_changed_static(rafthip_engine* e, rafthip_commit_pair* dst, uint64_t max_pairs,
+                                  uint64_t* n_changed) {
+    if (!e || !n_changed) return fail(RAFTHIP_EINVAL, "engine/count pointer is NULL");
+    if (max_pairs > 0 && !dst) return fail(RAFTHIP_EINVAL, "dst is NULL with max_pairs > 0");
+    if (e->stride > kStaticMaxGroups)
+        return fail(RAFTHIP_EINVAL, "rafthip_commit_changed_static serves engines of at most %llu groups (this one: %llu); "
+                                    "use rafthip_commit_changed", (u64)kStaticMaxGroups, (u64)e->G);
+    if (e->uniform && e->uniform_voters == 0 && !e->in_mask)
+        return fail(RAFTHIP_EINVAL, "rafthip_commit_changed_static: set a config first (the empty default needs mask planes, "
+                                    "which this entry point may not allocate)");
+    DeviceGuard guard(e->device);
+    Pair* d_out = nullptr;
+    if (max_pairs) {
+        d_out = device_addressable(dst);
+        if (!d_out)
+            return fail(RAFTHIP_EINVAL, "rafthip_commit_changed_static: dst must be device memory or page-locked host memory "
+                                        "(rafthip_host_alloc); a pageable buffer would need a landing buffer");
+    }
+    void* base = nullptr;
+    int rc = static_scratch(e->device, &base);  // resolved by rafthip_create: a table read
+    if (rc) return rc;
+    unsigned char* p = static_cast<unsigned char*>(base);
+    ReportBufs rb;
+    rb.bits = reinterpret_cast<u64*>(p);
+    rb.counts = reinterpret_cast<u32*>(p + kStaticBitsBytes);
+    rb.super = reinterpret_cast<u32*>(p + kStaticBitsBytes + kStaticCountsBytes);
+    rb.total = reinterpret_cast<u64*>(p + kStaticBitsBytes + kStaticCountsBytes + kStaticSuperBytes - 8);
+    rb.tiles_cap = (u32)(e->stride / kBlock);
+    if ((rc = report_pass<kChanged>(e, rb, 0, d_out, max_pairs))) return rc;
+    HIP_TRY(hipMemcpyAsync(e->h_scalar + 1, rb.total, sizeof(u64), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    *n_changed = e->h_scalar[1];
+    e->stats.changed_reported += *n_changed;
+    return RAFTHIP_OK;
+}
+
 int rafthip_upload_term_range(rafthip_engine* e, uint64_t first, uint64_t count, const uint64_t* term_first,
                               const uint64_t* term_last) {
     int rc = check_range(e, first, count);
@@ -1762,6 +1834,7 @@ int rafthip_heartbeat_commit(rafthip_engine* e, uint64_t first, uint64_t count, 
 }
 
 static_assert(kHeartbeatStride == RAFTHIP_HEARTBEAT_STRIDE, "heartbeat stride");
+static_assert(kStaticMaxGroups == RAFTHIP_STATIC_MAX_GROUPS, "static scratch limit");
 
 int rafthip_emit_heartbeats(rafthip_engine* e, uint64_t first, uint64_t count, uint8_t* out_bytes, uint8_t* out_len) {
     int rc = check_range(e, first, count);

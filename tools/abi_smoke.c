@@ -198,6 +198,12 @@ int main(void) {
     OK(rafthip_upload_commit(e, FIRST, COUNT, tf));
     OK(rafthip_commit_advance(e, pairs, 100, &np));
     OK(rafthip_commit_advance(e, NULL, 0, &np));
+    {   /* the allocation-free variant writes its pairs itself: page-locked landing buffer, sized to the byte */
+        void *pin = NULL;
+        OK(rafthip_host_alloc(&pin, 100 * sizeof *pairs));
+        OK(rafthip_commit_changed_static(e, pin, 100, &np));
+        OK(rafthip_host_free(pin));
+    }
     uint8_t *r8 = buf(COUNT), *g8 = buf(COUNT), *j8 = buf(COUNT);
     OK(rafthip_committed_in_term(e));
     OK(rafthip_read_committed_in_term(e, FIRST, COUNT, r8));
