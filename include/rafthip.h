@@ -469,6 +469,17 @@ int rafthip_step_wire(rafthip_engine *e, const uint8_t *bytes, const uint64_t *o
  * matchAckIndexer (tracker/tracker.go:164-175).  Result → commit plane. */
 int rafthip_commit(rafthip_engine *e);
 
+/* rafthip_commit for n engines — the shards one multi-raft host keeps on one
+ * GPU — as ONE kernel launch whose grid spans all of them, so the shards do not
+ * each pay a kernel boundary (at 2^20 groups per shard that boundary is a fifth
+ * of the pass).  Same results as calling rafthip_commit on each engine
+ * (tracker/tracker.go:179-181).  The single launch needs every engine on one
+ * GPU with the same uniform config of 1..8 voters (rafthip_set_uniform_config);
+ * any other set of engines is served engine by engine.  Runs on engines[0]'s
+ * stream; engines on other streams are joined to it with events, before and
+ * after.  Calls on any of the engines must not overlap this one. */
+int rafthip_commit_many(rafthip_engine *const *engines, uint32_t n);
+
 /* Same pass, but also reports the groups whose commit index differs from the
  * commit plane's previous content, sorted by group.  Waits for the GPU.
  * *n_changed = number of pairs; up to max_pairs of them are copied to dst
@@ -561,6 +572,65 @@ int rafthip_check_quorum(rafthip_engine *e);
  * yes-only map of read_only.go:68-76.  Output: VoteResult per group. */
 int rafthip_ack_quorum(rafthip_engine *e);
 int rafthip_read_ack_quorum(rafthip_engine *e, uint64_t first, uint64_t count, uint8_t *dst);
+
+/* ---- multi-GPU: the path's one exchange step, over RCCL / xGMI ----------- */
+
+/* Groups shard over the GPUs of a node by contiguous group-id range, one
+ * engine per GPU; no quorum computation couples two groups, so the only
+ * exchange is this one: after the commit pass every rank's changed (or
+ * advanced) (group, commit) pairs are all-gathered, so that the host loop that
+ * feeds raft.maybeCommit (raft.go:755-758) — and Ready's HardState.Commit
+ * (rawnode.go:141-156) — sees the whole node's set from any GPU.  Implemented
+ * against librccl: one count all-gather, one padded payload all-gather, one
+ * packing kernel.  The payload width of an exchange is guessed from the
+ * previous one (half again as much), so in steady state the two collectives
+ * and the packing run back to back with no host wait in between; a guess that
+ * turns out too small is repeated once, exact.  After rafthip_comm_create an
+ * exchange allocates nothing.
+ *
+ * A communicator binds one engine to one rank.  Ranks may be processes (one
+ * per GPU; distribute the id through any channel the host has) or threads of
+ * one process (each thread drives its own engine and communicator); a single
+ * thread that drives several GPUs uses rafthip_comm_create_all and
+ * rafthip_commit_allgather_many, which issue the collectives of all its ranks
+ * inside one RCCL group.  Calls on one communicator must be serialised, and
+ * every rank must make the same sequence of exchanges (it is a collective). */
+typedef struct rafthip_comm rafthip_comm;
+typedef struct rafthip_comm_id {
+    char bytes[128]; /* an ncclUniqueId */
+} rafthip_comm_id;
+
+/* On one rank; hand the id to the others. */
+int rafthip_comm_unique_id(rafthip_comm_id *id);
+/* Collective over the nranks ranks.  group_base = first global group id of this
+ * engine's shard (ranks own ascending ranges, so the gathered pairs come out
+ * sorted by global group id).  max_pairs_per_rank = most pairs one rank may
+ * contribute to an exchange, 0 = this engine's group count (the worst case);
+ * every rank ends up with the largest value any rank asked for.  Device memory:
+ * (2 * nranks + 1) * that many pairs of 16 bytes. */
+int rafthip_comm_create(rafthip_engine *e, const rafthip_comm_id *id, int rank, int nranks, uint64_t group_base,
+                        uint64_t max_pairs_per_rank, rafthip_comm **out);
+/* The same for n engines on n different GPUs of this process (rank i = engines[i]). */
+int rafthip_comm_create_all(rafthip_engine **engines, int n, const uint64_t *group_base, uint64_t max_pairs_per_rank,
+                            rafthip_comm **out);
+int rafthip_comm_destroy(rafthip_comm *c);
+int rafthip_comm_info(const rafthip_comm *c, int *rank, int *nranks, uint64_t *max_pairs_per_rank);
+
+/* rafthip_commit_changed (advance == 0) or rafthip_commit_advance (advance != 0)
+ * on this rank's engine, then the all-gather: dst receives up to max_pairs pairs
+ * of the WHOLE node, global group ids, sorted by group (host or device memory;
+ * NULL with max_pairs 0 = counts only); counts[nranks] (may be NULL) = pairs each
+ * rank reported; *n_total = their sum.  A rank that reports more than
+ * max_pairs_per_rank contributes only that many pairs (its count still says how
+ * many there were).  Waits for the GPU.  Consumer: raft.maybeCommit,
+ * raft.go:755-758. */
+int rafthip_commit_allgather(rafthip_comm *c, int advance, rafthip_commit_pair *dst, uint64_t max_pairs,
+                             uint64_t *counts, uint64_t *n_total);
+/* The same exchange for all n ranks that one thread drives: dst[i], max_pairs[i],
+ * counts[i], n_total[i] belong to comms[i] (dst / counts / their entries may be
+ * NULL). */
+int rafthip_commit_allgather_many(rafthip_comm **comms, int n, int advance, rafthip_commit_pair **dst,
+                                  const uint64_t *max_pairs, uint64_t **counts, uint64_t *n_total);
 
 /* ---- zero-copy access for hosts that fill planes on the GPU themselves --- */
 

@@ -45,7 +45,10 @@ SYMBOLS = [
     "rafthip_merge_acks", "rafthip_host_alloc", "rafthip_host_free",
     "rafthip_record_votes", "rafthip_read_votes", "rafthip_step_dense", "rafthip_upload_campaign",
     "rafthip_emit_heartbeats", "rafthip_plan_appends", "rafthip_commit_changed_static",
+    "rafthip_comm_unique_id", "rafthip_comm_create", "rafthip_comm_create_all", "rafthip_comm_destroy",
+    "rafthip_comm_info", "rafthip_commit_allgather", "rafthip_commit_allgather_many", "rafthip_commit_many",
 ]
+COMM_ID_BYTES = 128
 MSG_VOTE_RESP, MSG_PRE_VOTE_RESP = 6, 18
 
 STATE_PROBE, STATE_REPLICATE, STATE_SNAPSHOT, PROGRESS_PAUSED = 0, 1, 2, 4
@@ -138,6 +141,7 @@ def load_library():
         "rafthip_scatter_acks": (i32, [vp, vp, u64]),
         "rafthip_commit": (i32, [vp]),
         "rafthip_commit_changed": (i32, [vp, vp, u64, C.POINTER(u64)]),
+        "rafthip_commit_many": (i32, [C.POINTER(vp), u32]),
         "rafthip_commit_changed_static": (i32, [vp, vp, u64, C.POINTER(u64)]),
         "rafthip_read_commit": (i32, [vp, u64, u64, vp]),
         "rafthip_tally_votes": (i32, [vp]),
@@ -179,6 +183,14 @@ def load_library():
         "rafthip_step_dense": (i32, [vp, u64, u64, vp, u64, vp, vp, vp, u64]),
         "rafthip_record_votes": (i32, [vp, vp, u64]),
         "rafthip_read_votes": (i32, [vp, u64, u64, vp, u64]),
+        "rafthip_comm_unique_id": (i32, [vp]),
+        "rafthip_comm_create": (i32, [vp, vp, i32, i32, u64, u64, C.POINTER(vp)]),
+        "rafthip_comm_create_all": (i32, [C.POINTER(vp), i32, C.POINTER(u64), u64, C.POINTER(vp)]),
+        "rafthip_comm_destroy": (i32, [vp]),
+        "rafthip_comm_info": (i32, [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(u64)]),
+        "rafthip_commit_allgather": (i32, [vp, i32, vp, u64, vp, C.POINTER(u64)]),
+        "rafthip_commit_allgather_many": (i32, [C.POINTER(vp), i32, i32, C.POINTER(vp), C.POINTER(u64),
+                                                C.POINTER(vp), C.POINTER(u64)]),
         "rafthip_host_alloc": (i32, [C.POINTER(vp), u64]),
         "rafthip_host_free": (i32, [vp]),
     }
@@ -587,6 +599,75 @@ class Engine:
         p, st = C.c_void_p(), C.c_uint64()
         _check(self._L.rafthip_plane(self._h, which, C.byref(p), C.byref(st)))
         return p.value, st.value
+
+
+class EngineSet:
+    """A fixed list of engines for rafthip_commit_many (the handle array is built once)."""
+
+    def __init__(self, engines):
+        self.engines = list(engines)
+        self._L = load_library()
+        self._arr = (C.c_void_p * len(self.engines))(*[e._h for e in self.engines])
+
+    def commit(self, n=None):
+        """One launch over the first n engines (default: all)."""
+        _check(self._L.rafthip_commit_many(self._arr, len(self.engines) if n is None else n))
+
+
+def comm_unique_id():
+    """rafthip_comm_unique_id -> 128 bytes to hand to every rank (rank 0 calls this)."""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    _check(load_library().rafthip_comm_unique_id(buf))
+    return buf.raw
+
+
+class Comm:
+    """One rank of the path's exchange step (rafthip_comm_*): binds an Engine to a rank of an RCCL
+    communicator.  Creation is collective over the ranks."""
+
+    def __init__(self, engine, comm_id, rank, nranks, group_base=0, max_pairs_per_rank=0):
+        self._h = None
+        self._L = load_library()
+        self.engine = engine
+        idbuf = C.create_string_buffer(bytes(comm_id), COMM_ID_BYTES)
+        h = C.c_void_p()
+        _check(self._L.rafthip_comm_create(engine._h, idbuf, rank, nranks, group_base, max_pairs_per_rank, C.byref(h)))
+        self._h = h
+        r, n, cap = C.c_int(), C.c_int(), C.c_uint64()
+        _check(self._L.rafthip_comm_info(h, C.byref(r), C.byref(n), C.byref(cap)))
+        self.rank, self.nranks, self.max_pairs_per_rank = r.value, n.value, cap.value
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.rafthip_comm_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def commit_allgather(self, advance=False, max_pairs=None, dst=None):
+        """Commit pass + all-gather.  Returns (pairs of the whole node as numpy PAIR_DTYPE sorted by global
+        group id — or None when `dst`, a device / host address with room for max_pairs pairs, was given —,
+        per-rank counts, total)."""
+        if max_pairs is None:
+            max_pairs = self.nranks * self.max_pairs_per_rank
+        counts = np.zeros(self.nranks, dtype=np.uint64)
+        total = C.c_uint64()
+        out = None
+        if dst is None:
+            out = np.empty(max_pairs, dtype=PAIR_DTYPE)
+            dst = out
+        _check(self._L.rafthip_commit_allgather(self._h, int(bool(advance)), _ptr(dst) if max_pairs else None,
+                                                max_pairs, _ptr(counts), C.byref(total)))
+        if out is not None:
+            got = int(np.minimum(counts, self.max_pairs_per_rank).sum())
+            out = out[:min(got, max_pairs)]
+        return out, counts, total.value
 
 
 def batch_committed_index(match, in_mask, out_mask=None, device=0):

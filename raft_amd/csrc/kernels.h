@@ -324,6 +324,52 @@ __global__ __launch_bounds__(kCommitBlock) void k_commit_uniform(const u64* __re
 }
 
 // ---------------------------------------------------------------------------
+// K1m — the same pass over the shards of several engines of one GPU in ONE
+// launch (rafthip_commit_many).  A 2^20-group shard is a single wave of 512
+// workgroups and ends after 9 us, as long as the 1.5-1.9 us boundary between two
+// dependent kernels is a fifth of its run; a grid that spans the shards pays
+// that boundary once.  The shard table travels by value in the kernel arguments
+// (no device allocation); a workgroup finds its shard with a scalar search over
+// at most kManyMax tile offsets.
+// ---------------------------------------------------------------------------
+constexpr int kManyMax = 32;
+struct ManyShards {
+    u32 n;
+    u32 first_tile[kManyMax + 1];  // first_tile[k] = tiles of shards 0..k-1
+    const u64* match[kManyMax];
+    u64* commit[kManyMax];
+    u64 stride[kManyMax];
+};
+
+template <int V>
+__global__ __launch_bounds__(kCommitBlock) void k_commit_uniform_many(const ManyShards sh) {
+    u32 k = 0;
+    for (u32 i = 1; i < sh.n; ++i) k = blockIdx.x >= sh.first_tile[i] ? i : k;  // wave-uniform: scalar loads + compares
+    const u64* __restrict__ match = sh.match[k];
+    u64* __restrict__ commit = sh.commit[k];
+    const u64 stride = sh.stride[k];
+    const u64 base = (u64)(blockIdx.x - sh.first_tile[k]) * kTileGroups + threadIdx.x * 2;
+    Vec<u64, 2> in[kCH][V];
+#pragma unroll
+    for (int c = 0; c < kCH; ++c)
+#pragma unroll
+        for (int s = 0; s < V; ++s)
+            in[c][s] = load_stream<u64, 2>(match + (u64)s * stride + base + (u64)c * kCommitBlock * 2);
+#pragma unroll
+    for (int c = 0; c < kCH; ++c) {
+        Vec<u64, 2> res;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            u64 a[V];
+#pragma unroll
+            for (int s = 0; s < V; ++s) a[s] = in[c][s].v[j];
+            res.v[j] = committed_fixed<V>(a);
+        }
+        store_stream<u64, 2>(commit + base + (u64)c * kCommitBlock * 2, res);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // K2 — ProgressTracker.Committed with per-group joint configs, S <= 16 slots:
 // min(CommittedIndex(incoming), CommittedIndex(outgoing)), quorum/joint.go:49-56.
 // Both halves are sorted from the same loaded keys.  S <= 8: 512 lanes x 2
@@ -719,6 +765,25 @@ __global__ __launch_bounds__(kBlock) void k_pack_changed(const u64* __restrict__
             if (((b >> lane) & 1ull) && pos < max_pairs) out[pos] = Pair{group_base + g, commit[g]};
         }
     }
+}
+
+// ---------------------------------------------------------------------------
+// C1, after the all-gather: every rank's pairs sit in its own `width`-pair slot of
+// recv ([rank][width], only the first counts[rank] are meaningful); pack them into
+// one contiguous run in rank order — ranks own ascending group-id ranges, so the
+// run is sorted by global group id.  grid = (ceil(width / kBlock), nranks).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_pack_gathered(const Pair* __restrict__ recv,
+                                                          const u64* __restrict__ counts, u32 nranks,
+                                                          u64 width, Pair* __restrict__ out, u64 max_pairs) {
+    const u32 r = blockIdx.y;
+    const u64 i = (u64)blockIdx.x * kBlock + threadIdx.x;
+    if (r >= nranks) return;
+    const u64 mine = counts[r] < width ? counts[r] : width;
+    if (i >= mine) return;
+    u64 off = 0;
+    for (u32 k = 0; k < r; ++k) off += counts[k] < width ? counts[k] : width;
+    if (off + i < max_pairs) out[off + i] = recv[(u64)r * width + i];
 }
 
 // ---------------------------------------------------------------------------

@@ -2,6 +2,7 @@
 // and the C ABI declared in include/rafthip.h.  No torch, no CPU compute path:
 // every result comes from the gfx950 kernels in kernels.h.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
 
 #include <cstdarg>
 #include <cstdio>
@@ -1713,6 +1714,82 @@ int rafthip_commit(rafthip_engine* e) {
     return launch_commit<kStore>(e, &bg);
 }
 
+int rafthip_commit_many(rafthip_engine* const* engines, uint32_t n) {
+    if (!engines || n == 0) return fail(RAFTHIP_EINVAL, "engines is NULL or n is 0");
+    for (u32 i = 0; i < n; ++i)
+        if (!engines[i]) return fail(RAFTHIP_EINVAL, "engines[%u] is NULL", i);
+    rafthip_engine* e0 = engines[0];
+    // One launch needs: one GPU, the K1 shape (a uniform config of 1..8 voters, the same in every
+    // shard).  Anything else is the per-engine pass, engine by engine — same results.
+    bool one_launch = true, one_stream = true;
+    for (u32 i = 0; i < n; ++i) {
+        const rafthip_engine* e = engines[i];
+        if (e->device != e0->device || !e->uniform || e->uniform_voters != e0->uniform_voters) one_launch = false;
+        if (e->stream != e0->stream) one_stream = false;
+    }
+    if (e0->uniform_voters == 0 || e0->uniform_voters > 8) one_launch = false;
+    if (!one_launch) {
+        for (u32 i = 0; i < n; ++i) {
+            int rc = rafthip_commit(engines[i]);
+            if (rc) return rc;
+        }
+        return RAFTHIP_OK;
+    }
+    DeviceGuard guard(e0->device);
+    hipStream_t st = e0->stream;
+    hipEvent_t ev = nullptr;
+    if (!one_stream) {
+        // the launch runs on engines[0]'s stream: it waits for what the other engines' streams hold,
+        // and they wait for it
+        HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        for (u32 i = 1; i < n; ++i) {
+            if (engines[i]->stream == st) continue;
+            hipError_t err = hipEventRecord(ev, engines[i]->stream);
+            if (err == hipSuccess) err = hipStreamWaitEvent(st, ev, 0);
+            if (err != hipSuccess) {
+                (void)hipEventDestroy(ev);
+                return fail(RAFTHIP_EIO, "stream join: %s", hipGetErrorString(err));
+            }
+        }
+    }
+    int rc = RAFTHIP_OK;
+    for (u32 lo = 0; lo < n && !rc; lo += kManyMax) {
+        ManyShards sh{};
+        sh.n = n - lo < (u32)kManyMax ? n - lo : (u32)kManyMax;
+        u32 tiles = 0;
+        for (u32 k = 0; k < sh.n; ++k) {
+            rafthip_engine* e = engines[lo + k];
+            sh.first_tile[k] = tiles;
+            sh.match[k] = e->match;
+            sh.commit[k] = e->commit;
+            sh.stride[k] = e->stride;
+            tiles += (u32)((e->G + kTileGroups - 1) / kTileGroups);
+            e->stats.commit_launches++;
+            e->stats.groups_evaluated += e->G;
+        }
+        sh.first_tile[sh.n] = tiles;
+        switch (e0->uniform_voters) {
+#define RAFTHIP_CASE_MANY(V)                                                                             \
+    case V:                                                                                             \
+        hipLaunchKernelGGL((k_commit_uniform_many<V>), dim3(tiles), dim3(kCommitBlock), 0, st, sh);      \
+        break;
+            RAFTHIP_CASE_MANY(1) RAFTHIP_CASE_MANY(2) RAFTHIP_CASE_MANY(3) RAFTHIP_CASE_MANY(4)
+            RAFTHIP_CASE_MANY(5) RAFTHIP_CASE_MANY(6) RAFTHIP_CASE_MANY(7) RAFTHIP_CASE_MANY(8)
+#undef RAFTHIP_CASE_MANY
+        }
+        hipError_t err = hipGetLastError();
+        if (err != hipSuccess) rc = fail(RAFTHIP_EIO, "k_commit_uniform_many: %s", hipGetErrorString(err));
+    }
+    if (ev) {
+        hipError_t err = hipEventRecord(ev, st);
+        for (u32 i = 1; i < n && err == hipSuccess; ++i)
+            if (engines[i]->stream != st) err = hipStreamWaitEvent(engines[i]->stream, ev, 0);
+        (void)hipEventDestroy(ev);
+        if (err != hipSuccess && !rc) rc = fail(RAFTHIP_EIO, "stream join: %s", hipGetErrorString(err));
+    }
+    return rc;
+}
+
 int rafthip_commit_changed(rafthip_engine* e, rafthip_commit_pair* dst, uint64_t max_pairs,
                            uint64_t* n_changed) {
     return commit_report<kChanged>(e, dst, max_pairs, n_changed);
@@ -2055,6 +2132,348 @@ int rafthip_plane(rafthip_engine* e, int which, void** ptr, uint64_t* stride) {
     }
     if (stride) *stride = e->stride;
     return RAFTHIP_OK;
+}
+
+// ---- C1: the exchange step over RCCL ------------------------------------------
+}  // extern "C"
+
+struct rafthip_comm {
+    rafthip_engine* e = nullptr;
+    ncclComm_t nccl = nullptr;
+    int rank = 0, nranks = 1;
+    u64 group_base = 0;
+    u64 cap = 0;             // pairs per rank, equal on every rank
+    Pair* d_send = nullptr;  // [cap] this rank's pairs, global group ids
+    u64* d_counts = nullptr; // [nranks]
+    Pair* d_recv = nullptr;  // [nranks][width <= cap]
+    Pair* d_out = nullptr;   // [nranks * cap] landing buffer for a pageable dst
+    u64* h_counts = nullptr; // pinned [nranks]
+    u64 last_max = 0;        // largest per-rank count of the previous exchange
+    bool have_history = false;
+};
+
+namespace {
+
+#define NCCL_TRY(expr)                                                                              \
+    do {                                                                                            \
+        ncclResult_t _r = (expr);                                                                   \
+        if (_r != ncclSuccess) return fail(RAFTHIP_EIO, "%s: %s", #expr, ncclGetErrorString(_r));   \
+    } while (0)
+
+constexpr u64 kGatherGranule = 256;  // payload widths are multiples of this many pairs
+
+void comm_free(rafthip_comm* c) {
+    if (!c) return;
+    if (c->e) {
+        DeviceGuard guard(c->e->device);
+        if (c->e->stream) (void)hipStreamSynchronize(c->e->stream);
+        if (c->nccl) (void)ncclCommDestroy(c->nccl);
+        for (void* b : {(void*)c->d_send, (void*)c->d_counts, (void*)c->d_recv, (void*)c->d_out})
+            if (b) (void)hipFree(b);
+        if (c->h_counts) (void)hipHostFree(c->h_counts);
+    }
+    delete c;
+}
+
+// The small buffers of a communicator whose nccl handle, rank and nranks are set, and everything
+// the engine allocates lazily for a reporting pass, so that an exchange allocates nothing.
+int comm_finish_create(rafthip_comm* c) {
+    rafthip_engine* e = c->e;
+    int rc;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_counts), (size_t)c->nranks * sizeof(u64)));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_counts), (size_t)c->nranks * sizeof(u64), hipHostMallocDefault));
+    ReportBufs rb;
+    if ((rc = ensure_report_buffers(e, &rb))) return rc;  // so that the exchange itself allocates nothing
+    if ((rc = ensure(e, e->term_first, (size_t)e->stride * sizeof(u64)))) return rc;
+    if ((rc = ensure(e, e->term_last, (size_t)e->stride * sizeof(u64)))) return rc;
+    return RAFTHIP_OK;
+}
+
+int comm_alloc_payload(rafthip_comm* c) {
+    const size_t one = (size_t)c->cap * sizeof(Pair);
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_send), one));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_recv), one * c->nranks));
+    return RAFTHIP_OK;
+}
+
+// Enqueue the packing of the gathered slots into `out` (device-addressable) on c's stream.
+int enqueue_pack_gathered(rafthip_comm* c, u64 width, Pair* out, u64 max_pairs) {
+    if (width == 0 || max_pairs == 0) return RAFTHIP_OK;
+    const dim3 grid((u32)((width + kBlock - 1) / kBlock), (u32)c->nranks);
+    hipLaunchKernelGGL(k_pack_gathered, grid, dim3(kBlock), 0, c->e->stream, static_cast<const Pair*>(c->d_recv),
+                       static_cast<const u64*>(c->d_counts), (u32)c->nranks, width, out, max_pairs);
+    HIP_TRY(hipGetLastError());
+    return RAFTHIP_OK;
+}
+
+template <int MODE>
+int exchange_many(rafthip_comm** comms, int n, rafthip_commit_pair** dst, const uint64_t* max_pairs,
+                  uint64_t** counts_out, uint64_t* n_total) {
+    // 1. every engine's commit pass: pairs with global ids into its send buffer, count in *rb.total
+    ReportBufs rb[kMaxDevices];
+    for (int i = 0; i < n; ++i) {
+        rafthip_comm* c = comms[i];
+        DeviceGuard guard(c->e->device);
+        int rc = ensure_report_buffers(c->e, &rb[i]);  // allocated at create: a lookup
+        if (rc) return rc;
+        if ((rc = report_pass<MODE>(c->e, rb[i], c->group_base, c->d_send, c->cap))) return rc;
+    }
+    // 2. counts to every rank
+    if (n > 1) NCCL_TRY(ncclGroupStart());
+    for (int i = 0; i < n; ++i) {
+        rafthip_comm* c = comms[i];
+        DeviceGuard guard(c->e->device);
+        NCCL_TRY(ncclAllGather(rb[i].total, c->d_counts, 1, ncclUint64, c->nccl, c->e->stream));
+    }
+    if (n > 1) NCCL_TRY(ncclGroupEnd());
+    for (int i = 0; i < n; ++i) {
+        rafthip_comm* c = comms[i];
+        DeviceGuard guard(c->e->device);
+        HIP_TRY(hipMemcpyAsync(c->h_counts, c->d_counts, (size_t)c->nranks * sizeof(u64), hipMemcpyDeviceToHost, c->e->stream));
+    }
+    // 3. payload width: from the previous exchange when there was one (no host wait between the two
+    //    collectives; checked afterwards), else from the counts themselves
+    const rafthip_comm* c0 = comms[0];
+    u64 width = 0;
+    bool speculative = c0->have_history;
+    auto width_for = [&](u64 largest) {
+        u64 w = round_up(largest, kGatherGranule);
+        return w > c0->cap ? c0->cap : w;
+    };
+    auto largest_count = [&]() {
+        u64 m = 0;
+        for (int r = 0; r < c0->nranks; ++r) m = c0->h_counts[r] > m ? c0->h_counts[r] : m;
+        return m < c0->cap ? m : c0->cap;  // a rank sends at most cap pairs
+    };
+    if (speculative) {
+        width = width_for(c0->last_max + c0->last_max / 2 + 1);  // half again as much as last time
+    } else {
+        for (int i = 0; i < n; ++i) {
+            DeviceGuard guard(comms[i]->e->device);
+            HIP_TRY(hipStreamSynchronize(comms[i]->e->stream));
+        }
+        width = width_for(largest_count());
+    }
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (width) {
+            if (n > 1) NCCL_TRY(ncclGroupStart());
+            for (int i = 0; i < n; ++i) {
+                rafthip_comm* c = comms[i];
+                DeviceGuard guard(c->e->device);
+                NCCL_TRY(ncclAllGather(c->d_send, c->d_recv, (size_t)width * 2, ncclUint64, c->nccl, c->e->stream));
+            }
+            if (n > 1) NCCL_TRY(ncclGroupEnd());
+        }
+        for (int i = 0; i < n; ++i) {
+            rafthip_comm* c = comms[i];
+            DeviceGuard guard(c->e->device);
+            const u64 mp = (dst && dst[i] && max_pairs) ? max_pairs[i] : 0;
+            Pair* direct = mp ? device_addressable(dst[i]) : nullptr;  // else: through the landing buffer
+            const u64 room = direct ? mp : (mp < (u64)c->nranks * c->cap ? mp : (u64)c->nranks * c->cap);
+            int rc = enqueue_pack_gathered(c, width, direct ? direct : c->d_out, room);
+            if (rc) return rc;
+        }
+        for (int i = 0; i < n; ++i) {
+            DeviceGuard guard(comms[i]->e->device);
+            HIP_TRY(hipStreamSynchronize(comms[i]->e->stream));
+        }
+        const u64 need = width_for(largest_count());
+        if (need <= width) break;  // every rank's pairs fitted the slots that travelled
+        width = need;              // the guess was too small (same verdict on every rank): once more, exact
+    }
+    // 4. hand back
+    for (int i = 0; i < n; ++i) {
+        rafthip_comm* c = comms[i];
+        DeviceGuard guard(c->e->device);
+        u64 total = 0, delivered = 0;
+        for (int r = 0; r < c->nranks; ++r) {
+            total += c->h_counts[r];
+            delivered += c->h_counts[r] < c->cap ? c->h_counts[r] : c->cap;
+            if (counts_out && counts_out[i]) counts_out[i][r] = c->h_counts[r];
+        }
+        const u64 mp = (dst && dst[i] && max_pairs) ? max_pairs[i] : 0;
+        if (mp && !device_addressable(dst[i])) {
+            const u64 ncopy = delivered < mp ? delivered : mp;
+            if (ncopy) {
+                HIP_TRY(hipMemcpyAsync(dst[i], c->d_out, ncopy * sizeof(Pair), hipMemcpyDeviceToHost, c->e->stream));
+                HIP_TRY(hipStreamSynchronize(c->e->stream));
+                c->e->stats.bytes_downloaded += ncopy * sizeof(Pair);
+            }
+        }
+        if (n_total) n_total[i] = total;
+        const u64 mine = c->h_counts[c->rank];
+        if (MODE == kAdvance) {
+            c->e->stats.advanced_reported += mine;
+        } else {
+            c->e->stats.changed_reported += mine;
+        }
+        c->last_max = largest_count();
+        c->have_history = true;
+    }
+    return RAFTHIP_OK;
+}
+
+int check_comms(rafthip_comm** comms, int n) {
+    if (!comms || n < 1 || n > kMaxDevices) return fail(RAFTHIP_EINVAL, "comms is NULL or n outside [1, %d]", kMaxDevices);
+    for (int i = 0; i < n; ++i)
+        if (!comms[i] || !comms[i]->e || !comms[i]->nccl) return fail(RAFTHIP_EINVAL, "comms[%d] is not a live communicator", i);
+    return RAFTHIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+static_assert(sizeof(rafthip_comm_id) == sizeof(ncclUniqueId), "rafthip_comm_id must hold an ncclUniqueId");
+
+int rafthip_comm_unique_id(rafthip_comm_id* id) {
+    if (!id) return fail(RAFTHIP_EINVAL, "id is NULL");
+    ncclUniqueId u;
+    NCCL_TRY(ncclGetUniqueId(&u));
+    memcpy(id->bytes, &u, sizeof(u));
+    return RAFTHIP_OK;
+}
+
+// After the nccl handle exists: agree on the per-rank pair capacity (the largest any rank asked
+// for), then allocate.  max_pairs_per_rank 0 = this engine's group count.
+static int comm_agree_and_alloc(rafthip_comm* c, uint64_t max_pairs_per_rank) {
+    rafthip_engine* e = c->e;
+    int rc = comm_finish_create(c);
+    if (rc) return rc;
+    c->h_counts[c->rank] = max_pairs_per_rank ? max_pairs_per_rank : e->G;  // pinned: safe source of an async copy
+    HIP_TRY(hipMemcpyAsync(c->d_counts + c->rank, c->h_counts + c->rank, sizeof(u64), hipMemcpyHostToDevice, e->stream));
+    return RAFTHIP_OK;
+}
+
+int rafthip_comm_create(rafthip_engine* e, const rafthip_comm_id* id, int rank, int nranks, uint64_t group_base,
+                        uint64_t max_pairs_per_rank, rafthip_comm** out) {
+    if (!e || !id || !out) return fail(RAFTHIP_EINVAL, "engine/id/out is NULL");
+    *out = nullptr;
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fail(RAFTHIP_EINVAL, "rank %d outside [0, %d)", rank, nranks);
+    DeviceGuard guard(e->device);
+    rafthip_comm* c = new (std::nothrow) rafthip_comm();
+    if (!c) return fail(RAFTHIP_ENOMEM, "host allocation failed");
+    c->e = e;
+    c->rank = rank;
+    c->nranks = nranks;
+    c->group_base = group_base;
+    ncclUniqueId u;
+    memcpy(&u, id->bytes, sizeof(u));
+    int rc = RAFTHIP_OK;
+    do {
+        ncclResult_t r = ncclCommInitRank(&c->nccl, nranks, u, rank);
+        if (r != ncclSuccess) {
+            c->nccl = nullptr;
+            rc = fail(RAFTHIP_EIO, "ncclCommInitRank: %s", ncclGetErrorString(r));
+            break;
+        }
+        if ((rc = comm_agree_and_alloc(c, max_pairs_per_rank))) break;
+        // the capacity every rank uses = the largest one asked for: an in-place all-gather + max
+        r = ncclAllGather(c->d_counts + rank, c->d_counts, 1, ncclUint64, c->nccl, e->stream);
+        if (r != ncclSuccess) {
+            rc = fail(RAFTHIP_EIO, "ncclAllGather: %s", ncclGetErrorString(r));
+            break;
+        }
+        hipError_t err = hipMemcpyAsync(c->h_counts, c->d_counts, (size_t)nranks * sizeof(u64), hipMemcpyDeviceToHost, e->stream);
+        if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
+        if (err != hipSuccess) {
+            rc = fail(RAFTHIP_EIO, "capacity exchange: %s", hipGetErrorString(err));
+            break;
+        }
+        for (int k = 0; k < nranks; ++k) c->cap = c->h_counts[k] > c->cap ? c->h_counts[k] : c->cap;
+        c->cap = round_up(c->cap, kGatherGranule);
+        if ((rc = comm_alloc_payload(c))) break;
+        if ((rc = ensure(e, c->d_out, (size_t)c->cap * nranks * sizeof(Pair), false))) break;
+    } while (0);
+    if (rc) {
+        char keep[sizeof(g_err)];
+        memcpy(keep, g_err, sizeof(keep));
+        comm_free(c);
+        memcpy(g_err, keep, sizeof(keep));
+        return rc;
+    }
+    *out = c;
+    return RAFTHIP_OK;
+}
+
+int rafthip_comm_create_all(rafthip_engine** engines, int n, const uint64_t* group_base, uint64_t max_pairs_per_rank,
+                            rafthip_comm** out) {
+    if (!engines || !out || !group_base) return fail(RAFTHIP_EINVAL, "engines/group_base/out is NULL");
+    if (n < 1 || n > kMaxDevices) return fail(RAFTHIP_EINVAL, "n %d outside [1, %d]", n, kMaxDevices);
+    int devs[kMaxDevices];
+    u64 cap = max_pairs_per_rank;
+    for (int i = 0; i < n; ++i) {
+        out[i] = nullptr;
+        if (!engines[i]) return fail(RAFTHIP_EINVAL, "engines[%d] is NULL", i);
+        devs[i] = engines[i]->device;
+        for (int k = 0; k < i; ++k)
+            if (devs[k] == devs[i]) return fail(RAFTHIP_EINVAL, "engines %d and %d share device %d: one rank per GPU", k, i, devs[i]);
+        if (!max_pairs_per_rank && engines[i]->G > cap) cap = engines[i]->G;
+    }
+    cap = round_up(cap, kGatherGranule);
+    ncclComm_t handles[kMaxDevices];
+    NCCL_TRY(ncclCommInitAll(handles, n, devs));
+    int rc = RAFTHIP_OK;
+    for (int i = 0; i < n; ++i) {
+        rafthip_comm* c = new (std::nothrow) rafthip_comm();
+        if (!c) {
+            rc = fail(RAFTHIP_ENOMEM, "host allocation failed");
+            (void)ncclCommDestroy(handles[i]);
+            continue;
+        }
+        out[i] = c;
+        c->e = engines[i];
+        c->nccl = handles[i];
+        c->rank = i;
+        c->nranks = n;
+        c->group_base = group_base[i];
+        c->cap = cap;
+        if (rc) continue;
+        DeviceGuard guard(c->e->device);
+        if ((rc = comm_finish_create(c))) continue;
+        if ((rc = comm_alloc_payload(c))) continue;
+        rc = ensure(c->e, c->d_out, (size_t)c->cap * n * sizeof(Pair), false);
+    }
+    if (rc) {
+        char keep[sizeof(g_err)];
+        memcpy(keep, g_err, sizeof(keep));
+        for (int i = 0; i < n; ++i) {
+            comm_free(out[i]);
+            out[i] = nullptr;
+        }
+        memcpy(g_err, keep, sizeof(keep));
+    }
+    return rc;
+}
+
+int rafthip_comm_destroy(rafthip_comm* c) {
+    comm_free(c);
+    return RAFTHIP_OK;
+}
+
+int rafthip_comm_info(const rafthip_comm* c, int* rank, int* nranks, uint64_t* max_pairs_per_rank) {
+    if (!c) return fail(RAFTHIP_EINVAL, "comm is NULL");
+    if (rank) *rank = c->rank;
+    if (nranks) *nranks = c->nranks;
+    if (max_pairs_per_rank) *max_pairs_per_rank = c->cap;
+    return RAFTHIP_OK;
+}
+
+int rafthip_commit_allgather(rafthip_comm* c, int advance, rafthip_commit_pair* dst, uint64_t max_pairs,
+                             uint64_t* counts, uint64_t* n_total) {
+    int rc = check_comms(&c, 1);
+    if (rc) return rc;
+    if (max_pairs > 0 && !dst) return fail(RAFTHIP_EINVAL, "dst is NULL with max_pairs > 0");
+    return advance ? exchange_many<kAdvance>(&c, 1, &dst, &max_pairs, &counts, n_total)
+                   : exchange_many<kChanged>(&c, 1, &dst, &max_pairs, &counts, n_total);
+}
+
+int rafthip_commit_allgather_many(rafthip_comm** comms, int n, int advance, rafthip_commit_pair** dst,
+                                  const uint64_t* max_pairs, uint64_t** counts, uint64_t* n_total) {
+    int rc = check_comms(comms, n);
+    if (rc) return rc;
+    return advance ? exchange_many<kAdvance>(comms, n, dst, max_pairs, counts, n_total)
+                   : exchange_many<kChanged>(comms, n, dst, max_pairs, counts, n_total);
 }
 
 // ---- stateless one-shot forms ---------------------------------------------

@@ -4,13 +4,16 @@ tracker/tracker.go couples two groups), and the path's ONE exchange step: an
 all-gather of the changed (group, commit) pairs so that every rank (and the
 host loop that feeds raft.maybeCommit, raft.go:755-758) sees the full set.
 
-Backend: torch.distributed — "nccl" (= RCCL over xGMI) on GPUs, "gloo" in the
-CPU tests.  Two collectives per exchange: the per-rank counts, then one padded
-payload all-gather sized by the largest count.
+The exchange itself is in the product: librafthip.so's rafthip_comm_* /
+rafthip_commit_allgather run it over RCCL (include/rafthip.h); `make_comm` and
+`commit_changed_allgather(comm)` are thin callers.  What stays here in Python is
+the sharding arithmetic and a torch.distributed restatement of the exchange
+(`allgather_changed`, and `commit_changed_allgather` given a bare engine) that the
+CPU tests run over gloo to check that arithmetic without a GPU.
 """
 import numpy as np
 
-from .capi import PAIR_DTYPE
+from .capi import PAIR_DTYPE, Comm, comm_unique_id
 
 
 def shard_range(total_groups, rank, world):
@@ -84,13 +87,31 @@ def allgather_changed(pairs, group_base=0, device=None, group=None):
     return _allgather_pairs(buf, len(local), dist.get_world_size(group), group)
 
 
+def make_comm(engine, group_base=0, max_pairs_per_rank=0, group=None):
+    """The engine's communicator (rafthip_comm_create) over the ranks of the initialised
+    torch.distributed job — or a one-rank communicator without one.  Rank 0 draws the id; the
+    job's own process group only carries those 128 bytes."""
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized():
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+    else:
+        rank, world = 0, 1
+    box = [comm_unique_id() if rank == 0 else None]
+    if world > 1:
+        dist.broadcast_object_list(box, src=0, group=group)
+    return Comm(engine, box[0], rank, world, group_base, max_pairs_per_rank)
+
+
 def commit_changed_allgather(engine, group_base=0, device=None, group=None, max_pairs=None, advance=False):
-    """The path's one exchange step, without a host hop in the middle: the engine's
-    commit pass (rafthip_commit_changed, or rafthip_commit_advance with
-    advance=True) packs its pairs straight into a tensor on `device` (the GPU for
-    RCCL; host memory for gloo), group ids are rebased there, and the tensor is
-    all-gathered.  Returns (all pairs as numpy PAIR_DTYPE sorted by global group id,
-    this rank's pair count)."""
+    """The path's one exchange step.  Given a capi.Comm: rafthip_commit_allgather, the product
+    path over RCCL.  Given a bare engine (CPU tests over gloo): the same exchange restated on
+    torch.distributed — the engine's commit pass packs its pairs into a tensor on `device`,
+    group ids are rebased there, count all-gather, padded payload all-gather.  Returns (all
+    pairs as numpy PAIR_DTYPE sorted by global group id, this rank's pair count)."""
+    if isinstance(engine, Comm):
+        pairs, counts, _ = engine.commit_allgather(advance=advance, max_pairs=max_pairs)
+        return pairs, int(counts[engine.rank])
     import torch
     import torch.distributed as dist
 

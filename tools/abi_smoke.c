@@ -193,6 +193,7 @@ int main(void) {
     rafthip_commit_pair *pairs = buf(100 * sizeof *pairs); /* fewer than can change: the copy is clipped */
     uint64_t np = 0;
     OK(rafthip_commit(e));
+    OK(rafthip_commit_many(&e, 1));
     OK(rafthip_read_commit(e, FIRST, COUNT, com));
     OK(rafthip_commit_changed(e, pairs, 100, &np));
     OK(rafthip_upload_commit(e, FIRST, COUNT, tf));
@@ -237,6 +238,25 @@ int main(void) {
         memcpy(pin, acks, n * sizeof *acks);
         OK(rafthip_scatter_acks(e, pin, n));
         OK(rafthip_host_free(pin));
+    }
+    {   /* the exchange step on a one-rank communicator: per-rank form, then the one-thread-many-GPUs form */
+        rafthip_comm_id id;
+        rafthip_comm *c = NULL, *all[1] = {NULL};
+        uint64_t cnt[1] = {0}, tot = 0, cap = 0, base[1] = {1000000}, mp[1] = {100};
+        int r = -1, nr = -1;
+        OK(rafthip_comm_unique_id(&id));
+        OK(rafthip_comm_create(e, &id, 0, 1, 1000000, 0, &c));
+        OK(rafthip_comm_info(c, &r, &nr, &cap));
+        if (r != 0 || nr != 1 || cap < G) failures++;
+        OK(rafthip_commit_allgather(c, 0, pairs, 100, cnt, &tot)); /* host dst, clipped to 100 pairs */
+        OK(rafthip_commit_allgather(c, 1, NULL, 0, NULL, &tot));
+        OK(rafthip_comm_destroy(c));
+        OK(rafthip_comm_create_all(&e, 1, base, 0, all));
+        rafthip_commit_pair *dsts[1] = {pairs};
+        uint64_t *cnts[1] = {cnt};
+        OK(rafthip_commit_allgather_many(all, 1, 0, dsts, mp, cnts, &tot));
+        OK(rafthip_comm_destroy(all[0]));
+        FAILS(rafthip_comm_create(e, &id, 1, 1, 0, 0, &c)); /* rank outside [0, nranks) */
     }
     OK(rafthip_destroy(e));
     if (failures) {

@@ -9,7 +9,8 @@ out=$root/tools/bin/asan
 mkdir -p "$out"
 if [ "$1" = "build" ] || [ ! -x "$out/rafthost_cli" ]; then
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -shared -Xarch_host -fsanitize=address \
-      -I"$root/include" -I"$root/raft_amd/csrc" -o "$out/librafthip.so" "$root/raft_amd/csrc/rafthip.hip"
+      -I"$root/include" -I"$root/raft_amd/csrc" -o "$out/librafthip.so" "$root/raft_amd/csrc/rafthip.hip" \
+      -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
   /opt/rocm/lib/llvm/bin/clang++ -O1 -g -std=c++17 -fsanitize=address -I"$root/include" -I"$root/raft_amd/host" \
       -o "$out/rafthost_cli" "$root"/raft_amd/host/{hostcli,quorum_batch,tracker_batch}.cpp \
       -L"$out" -lrafthip -Wl,-rpath,'$ORIGIN' -Wl,-rpath-link,/opt/rocm/lib
