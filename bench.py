@@ -3,24 +3,37 @@
 
 Metric (BASELINE.json): quorum evals/sec (groups/s) at 1M x 5 voters.
 
-A "step" is one ProgressTracker.Committed pass (K1, k_commit_uniform<5>) over
-one batch of 2^20 Raft groups x 5 voters, non-joint, dist A
+A "step" is one ProgressTracker.Committed pass (K1, sorting network over 5 Match
+planes) over one batch of 2^20 Raft groups x 5 voters, non-joint, dist A
 (quorum/bench_test.go:30-33), with Match planes already resident in HBM.  One
-batch is 40 MiB in + 8 MiB out — smaller than the 256 MiB Infinity Cache — so
-the steps rotate over --batches distinct resident batches (default 12, 576 MiB)
-to make every pass read cold HBM instead of re-reading a cached batch.
+batch is 40 MiB in + 8 MiB out — smaller than the 256 MiB Infinity Cache — so the
+steps rotate over --batches distinct resident batches (default 12, 576 MiB) to
+make every pass read cold HBM.  The batches are the shards a multi-raft host keeps
+on one GPU; rafthip_commit_many runs L of them per kernel launch (L steps per
+launch, every launch of a run the same L, so the per-kernel average rocprofv3
+reports is the figure `roofline` is computed from).
 
-N > 1: one process per GPU (torch.distributed / RCCL for the barrier and the
-max-over-ranks); groups shard by group-id range, every rank runs the same
-steps on its own shard (weak scaling, no data-path collective).  The one
-exchange step of the design — the all-gather of changed (group, commit) pairs
-— is timed separately after the main loop and reported under "extra".
+N > 1: one process per GPU.  `python bench.py --gpus N` starts the N ranks itself
+(fresh child processes, before anything touches a GPU); under
+torch.distributed.run (WORLD_SIZE set) the process is one of the ranks.  Groups
+shard by group-id range, every rank runs the same steps on its own shard (weak
+scaling, no data-path collective); torch.distributed / RCCL carries the barrier and
+the max-over-ranks.  The one exchange step of the design — the all-gather of
+changed (group, commit) pairs, rafthip_commit_allgather over RCCL — is timed
+separately after the main loop and reported under "extra".
+
+--config cfg3 | cfg5 run the two BASELINE configs that are defined across GPUs
+(16M joint groups sharded; MsgAppResp scatter -> commit with acks routed by group
+range) as the workload; at N = 1 the default run also reports both under "extra".
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
+import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -34,6 +47,9 @@ G_BATCH = 1 << 20
 VOTERS = 5
 BYTES_PER_GROUP = VOTERS * 8 + 8  # 5 Match loads + 1 commit store
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: 8.0 TB/s spec
+ATOMIC_RATE_PEAK = 26.6e9         # scattered 8-byte atomics/s, measured (tools/scatter_probe.py)
+CFG3_GROUPS = 1 << 24             # BASELINE configs[2]: 16M groups, joint, across the GPUs
+CFG5_GROUPS = 1 << 24             # BASELINE configs[4]: 7 voters + 2 learners, 4 acks per group
 CPU_EXTRA = {}
 
 
@@ -42,13 +58,77 @@ def splitmix_batch(seed, S, G):
     return gu.dist_a(seed, S, G)
 
 
+# ---------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` without a rank environment
+# ---------------------------------------------------------------------------------------------
+
+def launch_ranks(n, argv):
+    """Start n fresh rank processes of this script (the parent never touches a GPU, never execs
+    after GPU init), pass rank 0's stdout through, return the worst exit code."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RAFTHIP_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode]
+    deadline = time.time() + 120
+    for p in procs[1:]:
+        try:
+            rcs.append(p.wait(timeout=max(1.0, deadline - time.time())))
+        except subprocess.TimeoutExpired:
+            p.kill()  # exactly the child we started
+            rcs.append(-9)
+    sys.stdout.write(out.decode("utf-8", "replace"))
+    sys.stdout.flush()
+    return max((abs(rc) for rc in rcs), default=0)
+
+
+# ---------------------------------------------------------------------------------------------
+# CPU baseline
+# ---------------------------------------------------------------------------------------------
+
+def usable_cpus():
+    """CPUs this process may use: the affinity mask, cut by a cgroup CPU quota when one is set."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            quota, period = open(path).read().split()[:2]
+            if quota != "max":
+                n = max(1, min(n, int(math.ceil(int(quota) / int(period)))))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline(match, seconds=10.0):
-    """The oracle's reference-shaped loop (per-group id set + id-keyed map,
-    CommittedIndex per group) on the host cores.  A baseline, not the product."""
+    """The oracle's reference-shaped loop (per-group id set + id-keyed map, CommittedIndex per
+    group) on the host cores.  A baseline, not the product.  Thread counts from the box's
+    OMP_NUM_THREADS share up to every host core are tried briefly; the fastest one runs the sample."""
     import oracle
-    threads = min(16, os.cpu_count() or 1)
+    host_cores = os.cpu_count() or 1
+    usable = usable_cpus()
+    omp = int(os.environ.get("OMP_NUM_THREADS", "0") or 0)
+    tried = {}
     cb = oracle.CpuBaseline(match, VOTERS)
-    used = cb.run(threads)  # warm-up pass
+    for t in sorted({c for c in (omp, 16, usable, host_cores) if 0 < c <= host_cores}):
+        cb.run(t)  # warm-up pass
+        k, a = 0, time.perf_counter()
+        while time.perf_counter() - a < 1.0:
+            cb.run(t)
+            k += 1
+        tried[t] = k * match.shape[1] / (time.perf_counter() - a)
+    threads = max(tried, key=tried.get)
+    used = cb.run(threads)
     n, t0 = 0, time.perf_counter()
     while True:
         cb.run(threads)
@@ -71,31 +151,171 @@ def cpu_baseline(match, seconds=10.0):
                       "cpu_best_soa_groups_per_s": soa_rate, "cpu_best_soa_threads": soa_threads})
     return {
         "value": n * match.shape[1] / dt, "unit": "groups/s", "cores": int(used), "kind": "port",
-        "sample": "%d passes over one 2^20-group x 5-voter dist-A batch (%.1f s wall, %d OpenMP threads), "
-                  "oracle/quorum_oracle.c map-shaped CommittedIndex loop" % (n, dt, used),
+        "host_cores": host_cores, "usable_cores": usable, "threads": int(used),
+        "threads_tried_groups_per_s": {str(t): round(v) for t, v in sorted(tried.items())},
+        "sample": "%d passes over one 2^20-group x 5-voter dist-A batch (%.1f s wall, %d OpenMP threads — the fastest of "
+                  "the thread counts tried, %d host cores), oracle/quorum_oracle.c map-shaped CommittedIndex loop"
+                  % (n, dt, used, host_cores),
     }, ref
 
+
+# ---------------------------------------------------------------------------------------------
+# the BASELINE configs that are defined across GPUs
+# ---------------------------------------------------------------------------------------------
+
+def _timed(stream, fn, reps):
+    import torch
+    with torch.cuda.stream(stream):
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record(stream)
+        for _ in range(reps):
+            fn()
+        ev1.record(stream)
+        ev1.synchronize()
+    return ev0.elapsed_time(ev1) * 1e-3 / reps
+
+
+def run_cfg3(raft_amd, torch, dev, local_rank, stream, rank, world, reps):
+    """BASELINE configs[2] / SURVEY.md §8(d) cfg3: 2^24 groups over the ranks, S = 6 slots:
+    80 % joint (incoming 5, outgoing 5, overlap 4: slot 4 replaced by slot 5), 10 % non-joint
+    V = 5, 10 % asymmetric (outgoing 3 -> incoming 5).  Returns (figures, engine, seconds per pass)."""
+    import oracle
+    from raft_amd import multigpu
+    first, G = multigpu.shard_range(CFG3_GROUPS, rank, world)
+    S = 6
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(0x5EED0003 + rank)
+    match = torch.randint(0, (1 << 62), (S, G), dtype=torch.int64, device=dev, generator=gen)
+    kind = torch.randint(0, 10, (G,), device=dev, generator=gen)
+    in_mask = torch.full((G,), 0b011111, dtype=torch.uint8, device=dev)
+    out_mask = torch.where(kind < 8, 0b101111, 0)
+    out_mask = torch.where(kind == 9, 0b000111, out_mask).to(torch.uint8).contiguous()
+    e = raft_amd.Engine(G, S, device=local_rank, stream=stream.cuda_stream)
+    try:
+        e.upload_config(in_mask, out_mask)
+        e.upload_match(match)
+        with torch.cuda.stream(stream):
+            e.commit()
+        torch.cuda.synchronize()
+        n = min(G, 8192)  # oracle = checker, on a slice
+        want = oracle.batch_committed(match[:, :n].cpu().numpy().astype(np.uint64), in_mask[:n].cpu().numpy(),
+                                      out_mask[:n].cpu().numpy())
+        if not np.array_equal(e.read_commit(0, n), want):
+            raise SystemExit("bench cfg3: GPU result differs from the oracle")
+        del match, kind
+        sec = _timed(stream, e.commit, reps)
+        bytes_per_group = 8 * S + 2 + 8  # SURVEY.md §8(d): 58 B at S = 6
+        return {"groups_total": CFG3_GROUPS, "groups_this_rank": G, "slots": S, "ms_per_pass": round(sec * 1e3, 4),
+                "groups_per_s_this_rank": G / sec, "GBs": round(G * bytes_per_group / sec / 1e9, 1),
+                "frac_of_hbm_peak": round(G * bytes_per_group / sec / 1e9 / HBM_PEAK_GBS, 4),
+                "kernel": "k_commit_masked<6>", "bytes_per_group": bytes_per_group}, e, sec
+    except BaseException:
+        e.close()
+        raise
+
+
+def run_cfg5(raft_amd, torch, dev, local_rank, stream, rank, world, reps):
+    """BASELINE configs[4] / SURVEY.md §8(d) cfg5: 2^24 groups over the ranks, 7 voters + 2 learners
+    (S = 9 rows, quorum over 7); per pass 4 acks per group, uniformly random cell, index = the cell's
+    old Match + U[-3, 61) (about 5 % stale), routed to the owning rank by group range; then the commit pass."""
+    from raft_amd import multigpu
+    first, G = multigpu.shard_range(CFG5_GROUPS, rank, world)
+    S, V = 9, 7
+    n_acks = 4 * G
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(0x5EED0005 + rank)
+    base = 1 << 30
+    e = raft_amd.Engine(G, S, device=local_rank, stream=stream.cuda_stream)
+    e.set_uniform_config(V)
+    e.upload_match(torch.full((S, G), base, dtype=torch.int64, device=dev))
+    # rafthip_ack records {u32 group, u32 slot, u64 index} as int64 pairs, built on the device:
+    # what a host has after routing the node's ack stream by group range (multigpu.route_acks)
+    grp = torch.randint(0, G, (n_acks,), dtype=torch.int64, device=dev, generator=gen)
+    slot = torch.randint(0, S, (n_acks,), dtype=torch.int64, device=dev, generator=gen)
+    recs = torch.empty((n_acks, 2), dtype=torch.int64, device=dev)
+    recs[:, 0] = grp | (slot << 32)
+    del grp, slot
+    bump = [0]
+
+    def one_pass():
+        # every pass acknowledges a little further than the last one, so the atomics really update
+        recs[:, 1] = base + bump[0] * 64 + torch.randint(-3, 61, (n_acks,), dtype=torch.int64, device=dev, generator=gen)
+        bump[0] += 1
+
+    try:
+        import oracle
+        with torch.cuda.stream(stream):
+            one_pass()
+            e.scatter_acks(recs.data_ptr(), n_acks)
+            e.commit()
+        torch.cuda.synchronize()
+        n = min(G, 8192)  # oracle = checker, on a slice: the commit pass over the scattered planes
+        if not np.array_equal(e.read_commit(0, n), oracle.batch_committed(e.read_match(0, n), uniform_voters=V)):
+            raise SystemExit("bench cfg5: GPU result differs from the oracle")
+        t_sc = t_co = 0.0
+        for _ in range(reps):
+            with torch.cuda.stream(stream):
+                one_pass()
+            torch.cuda.synchronize()
+            t_sc += _timed(stream, lambda: e.scatter_acks(recs.data_ptr(), n_acks), 1)
+            t_co += _timed(stream, e.commit, 1)
+        t_sc /= reps
+        t_co /= reps
+        sec = t_sc + t_co
+        return {"groups_total": CFG5_GROUPS, "groups_this_rank": G, "acks_this_rank": n_acks, "slots": S, "voters": V,
+                "scatter_ms": round(t_sc * 1e3, 4), "commit_ms": round(t_co * 1e3, 4),
+                "groups_per_s_this_rank": G / sec, "acks_per_s_this_rank": n_acks / t_sc,
+                "scatter_frac_of_hbm_peak": round(n_acks * 24 / t_sc / 1e9 / HBM_PEAK_GBS, 4),
+                "scatter_frac_of_atomic_rate": round(n_acks / t_sc / ATOMIC_RATE_PEAK, 4),
+                "commit_frac_of_hbm_peak": round(G * 64 / t_co / 1e9 / HBM_PEAK_GBS, 4)}, e, sec
+    except BaseException:
+        e.close()
+        raise
+
+
+# ---------------------------------------------------------------------------------------------
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--batches", type=int, default=12, help="distinct resident batches to rotate over")
+    ap.add_argument("--batches", type=int, default=12, help="distinct resident batches (shards) to rotate over")
+    ap.add_argument("--shards-per-launch", type=int, default=0,
+                    help="steps per rafthip_commit_many launch (0: the largest divisor of gcd(steps, warmup) <= --batches)")
+    ap.add_argument("--config", choices=["headline", "cfg3", "cfg5"], default="headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="headline only (profiling runs)")
     args = ap.parse_args()
+
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        # no rank environment: be the launcher.  Nothing above has touched a GPU.
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    world = int(env_world or "1")
+    if world != args.gpus:
+        raise SystemExit("bench.py: WORLD_SIZE=%d but --gpus %d; launch %d ranks (or drop the rank environment and "
+                         "let `python bench.py --gpus %d` start them)" % (world, args.gpus, args.gpus, args.gpus))
+
+    # The contract is ONE JSON line on stdout.  RCCL prints a version banner on stdout when a
+    # communicator comes up (gloo a connection notice): from here on file descriptor 1 is stderr, and the
+    # line goes to the saved descriptor.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        os.write(json_fd, (json.dumps(obj) + "\n").encode())
 
     import torch
     import torch.distributed as dist
 
     import raft_amd
+    from raft_amd import multigpu
+    from raft_amd.capi import EngineSet
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the engine has no CPU path)")
     # Rehearsal on a one-GPU box (RAFTHIP_BENCH_REHEARSE=1): every rank drives cuda:0 and the
@@ -105,7 +325,7 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    cdev = torch.device("cpu") if rehearse else dev  # where collective payloads live
+    cdev = torch.device("cpu") if rehearse else dev  # where torch's collective payloads live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearse:
@@ -114,9 +334,74 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
 
     stream = torch.cuda.Stream(device=dev)
-    engines = []
-    mats = []
-    for b in range(args.batches):
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(*vals):
+        if world == 1:
+            return [float(v) for v in vals]
+        t = torch.tensor(list(vals), dtype=torch.float64, device=cdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return [float(x) for x in t]
+
+    import oracle
+
+    extra = {}
+    K, W = args.steps, args.warmup
+
+    if args.config != "headline":
+        # One of the cross-GPU BASELINE configs as the workload: strong scaling, total groups fixed.
+        # cfg3: K commit passes between the barriers, wall clock.  cfg5: a step = scatter + commit, timed
+        # per step with HIP events inside the runner (the synthetic acks are refreshed between steps,
+        # untimed); the step time is the mean over min(K, 20) steps.
+        if args.config == "cfg3":
+            info, e, _ = run_cfg3(raft_amd, torch, dev, local_rank, stream, rank, world, max(1, min(W, 3)))
+            with torch.cuda.stream(stream):
+                barrier()
+                t0 = time.perf_counter()
+                for _ in range(K):
+                    e.commit()
+                barrier()
+                wall = time.perf_counter() - t0
+            total = CFG3_GROUPS
+        else:
+            info, e, sec = run_cfg5(raft_amd, torch, dev, local_rank, stream, rank, world, max(1, min(K, 20)))
+            barrier()
+            wall = sec * K
+            total = CFG5_GROUPS
+        (wall,) = max_over_ranks(wall)
+        if rank == 0:
+            out = {"metric": "quorum evals/sec (groups/s), BASELINE %s" % args.config, "value": total * K / wall,
+                   "unit": "groups/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": 1e3 * wall / K,
+                   "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+                   "config": {"workload": ("cfg3: 2^24 groups x 6 slots, joint mix, ProgressTracker.Committed, sharded by group range"
+                                           if args.config == "cfg3" else
+                                           "cfg5: 2^24 groups x (7 voters + 2 learners), 2^26 MsgAppResp acks per step routed by "
+                                           "group range -> atomicMax scatter -> commit pass; step time by HIP events"),
+                              "groups_total": total, "sharding": "group-id range, no data-path collective"},
+                   "extra": {"rank0": info}}
+            if args.config == "cfg3":
+                ach = info["groups_this_rank"] * info["bytes_per_group"] / (wall / K) / 1e9
+                out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": ach / HBM_PEAK_GBS, "traffic": None, "kernel": info["kernel"]}
+            else:
+                out["roofline"] = {"bound": "atomic-rate", "achieved": info["acks_per_s_this_rank"], "peak": ATOMIC_RATE_PEAK,
+                                   "unit": "atomics/s", "frac": info["scatter_frac_of_atomic_rate"], "traffic": None,
+                                   "kernel": "k_scatter_acks", "frac_of_hbm_peak": info["scatter_frac_of_hbm_peak"]}
+            emit(out)
+        e.close()
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    # ---- headline -----------------------------------------------------------------------------
+    nb = args.batches
+    engines, mats = [], []
+    for b in range(nb):
         # group-id range of this rank's shard of batch b: seeds differ per (rank, batch)
         m = splitmix_batch(0x5EED0000 + 1000 * rank + b, VOTERS, G_BATCH)
         e = raft_amd.Engine(G_BATCH, VOTERS, device=local_rank, stream=stream.cuda_stream)
@@ -126,151 +411,124 @@ def main():
         mats.append(m)
     first_match = mats[0]
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+    # Every launch covers the same number L of shards (= steps), warm-up included.
+    L = args.shards_per_launch
+    if L <= 0:
+        g = math.gcd(K, W) if W > 0 else K
+        L = max(d for d in range(1, min(nb, g) + 1) if g % d == 0)
+    L = max(1, min(L, nb))
+    # rotation: launch j covers shards (j*L .. j*L+L-1) mod nb; one EngineSet per distinct start
+    sets = {}
+    for start in range(0, nb * L, L):
+        s0 = start % nb
+        if s0 not in sets:
+            sets[s0] = EngineSet([engines[(s0 + i) % nb] for i in range(L)])
 
-    def run(n):
-        nb = len(engines)
-        for i in range(n):
-            engines[i % nb].commit()
+    def run(n_steps, at=0):
+        """n_steps steps as launches of L shards (+ one shorter launch if L does not divide n_steps)."""
+        launches, pos = 0, at
+        while n_steps > 0:
+            take = min(L, n_steps)
+            sets[pos % nb].commit(take)
+            pos += take
+            n_steps -= take
+            launches += 1
+        return launches, pos
 
     with torch.cuda.stream(stream):
-        run(args.warmup)
+        _, pos = run(W)
         barrier()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
         ev0.record(stream)
-        run(args.steps)
+        n_launches, pos = run(K, pos)
         ev1.record(stream)
         barrier()
         t1 = time.perf_counter()
     wall = t1 - t0
     gpu_ms = ev0.elapsed_time(ev1)
-
-    if world > 1:
-        t = torch.tensor([wall, gpu_ms], dtype=torch.float64, device=cdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall, gpu_ms = float(t[0]), float(t[1])
+    wall, gpu_ms = max_over_ranks(wall, gpu_ms)
 
     # correctness spot check of what was timed (oracle = checker only)
-    import oracle
     got = engines[0].read_commit()
     idx = np.arange(0, G_BATCH, 4099)
     want = oracle.batch_committed(np.ascontiguousarray(first_match[:, idx]), uniform_voters=VOTERS)
     if not np.array_equal(got[idx], want):
         raise SystemExit("bench: GPU result differs from the oracle")
 
-    extra = {}
-    # single-launch latency (launch + kernel + sync), the floor a host sees at G = 2^20
-    with torch.cuda.stream(stream):
-        lat = []
-        for i in range(50):
-            torch.cuda.synchronize()
+    extra["shards_per_launch"] = L
+    extra["launches_timed"] = n_launches
+    if not args.no_extras:
+        # the single-engine entry point, one 2^20-group shard per launch on one stream (round 1's headline
+        # shape): what a host with ONE shard per GPU per tick gets
+        with torch.cuda.stream(stream):
+            for i in range(50):
+                engines[i % nb].commit()
+            ev2, ev3 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev2.record(stream)
+            for i in range(600):
+                engines[i % nb].commit()
+            ev3.record(stream)
+            ev3.synchronize()
+        one_us = 1e3 * ev2.elapsed_time(ev3) / 600
+        extra["one_shard_per_launch_avg_us"] = round(one_us, 3)
+        extra["one_shard_per_launch_frac_of_hbm_peak"] = round(BYTES_PER_GROUP * G_BATCH / (one_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+
+        # single-launch latency (launch + kernel + sync), the floor a host sees at G = 2^20
+        with torch.cuda.stream(stream):
+            lat = []
+            for i in range(50):
+                torch.cuda.synchronize()
+                a = time.perf_counter()
+                engines[i % nb].commit()
+                torch.cuda.synchronize()
+                lat.append(time.perf_counter() - a)
+        extra["single_launch_sync_us"] = round(1e6 * float(np.median(lat)), 2)
+
+        # the same pass when one engine's planes stay cache-resident between ticks (48 MiB < the
+        # 256 MiB Infinity Cache): what a host with ONE 2^20-group engine per GPU sees; not `value`
+        with torch.cuda.stream(stream):
+            ev2, ev3 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for _ in range(50):
+                engines[0].commit()
+            ev2.record(stream)
+            for _ in range(500):
+                engines[0].commit()
+            ev3.record(stream)
+            ev3.synchronize()
+        extra["same_batch_avg_launch_us"] = round(1e3 * ev2.elapsed_time(ev3) / 500, 3)
+
+        # on-box streaming ceiling (SURVEY.md §8d): a device-to-device copy of 1 GiB, read + write bytes
+        if rank == 0:
+            a_t = torch.empty(1 << 28, dtype=torch.int32, device=dev)
+            b_t = torch.empty_like(a_t)
+            with torch.cuda.stream(stream):
+                for _ in range(3):
+                    b_t.copy_(a_t)
+                ev4, ev5 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev4.record(stream)
+                for _ in range(10):
+                    b_t.copy_(a_t)
+                ev5.record(stream)
+                ev5.synchronize()
+            extra["dtod_copy_GBs"] = round(10 * 2 * a_t.numel() * 4 / (ev4.elapsed_time(ev5) * 1e-3) / 1e9, 1)
+            del a_t, b_t
+
+        # the stateless entry point (what quorum.BatchCommittedIndex binds to): pageable host planes in,
+        # host result out — the PCIe-inclusive rate, never `value`
+        if rank == 0:
+            full = np.full(G_BATCH, (1 << VOTERS) - 1, dtype=np.uint8)
+            raft_amd.batch_committed_index(first_match, full, device=local_rank)
             a = time.perf_counter()
-            engines[i % len(engines)].commit()
-            torch.cuda.synchronize()
-            lat.append(time.perf_counter() - a)
-    extra["single_launch_sync_us"] = round(1e6 * float(np.median(lat)), 2)
-
-    # the same pass when one engine's planes stay cache-resident between ticks (48 MiB < the
-    # 256 MiB Infinity Cache): what a host with ONE 2^20-group engine per GPU sees; not `value`
-    with torch.cuda.stream(stream):
-        ev2, ev3 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        for _ in range(50):
-            engines[0].commit()
-        ev2.record(stream)
-        for _ in range(500):
-            engines[0].commit()
-        ev3.record(stream)
-        ev3.synchronize()
-    extra["same_batch_avg_launch_us"] = round(1e3 * ev2.elapsed_time(ev3) / 500, 3)
-
-    # HIP-graph-amortised launch (SURVEY.md §8d caveat): one rotation over all batches captured
-    # on the engine stream and replayed — the per-launch host cost is gone, what remains is the
-    # kernel plus the kernel-to-kernel boundary on the device
-    try:
-        if world > 1:  # single-GPU measurement extra: no stream capture next to a live RCCL communicator
-            raise RuntimeError("skipped at n_gpus > 1")
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, stream=stream):
-            for e in engines:
-                e.commit()
-        with torch.cuda.stream(stream):
             for _ in range(5):
-                graph.replay()
-            ev6, ev7 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            reps = max(1, 1200 // len(engines))
-            ev6.record(stream)
-            for _ in range(reps):
-                graph.replay()
-            ev7.record(stream)
-            ev7.synchronize()
-        extra["hip_graph_avg_launch_us"] = round(1e3 * ev6.elapsed_time(ev7) / (reps * len(engines)), 3)
-        del graph
-    except Exception as ex:  # capture is a measurement extra, never the headline
-        extra["hip_graph_avg_launch_us"] = None
-        extra["hip_graph_error"] = str(ex)[:200]
+                one = raft_amd.batch_committed_index(first_match, full, device=local_rank)
+            extra["oneshot_host_buffers_groups_per_s"] = 5 * G_BATCH / (time.perf_counter() - a)
+            if not np.array_equal(one[idx], want):
+                raise SystemExit("bench: one-shot result differs from the oracle")
 
-    # the same rotation with every engine on its OWN stream (what rafthip_create gives an engine by
-    # default): passes over different engines are independent, so one pass's drain overlaps the
-    # next one's ramp-up.  Aggregate throughput of a host with several shards per GPU; not `value`
-    # (the headline keeps one stream so that its per-launch duration is the kernel's own).
-    if rank == 0 and world == 1:
-        own = []
-        for m in mats:
-            e = raft_amd.Engine(G_BATCH, VOTERS, device=local_rank)
-            e.set_uniform_config(VOTERS)
-            e.upload_match(m)
-            own.append(e)
-        for i in range(200):
-            own[i % len(own)].commit()
-        torch.cuda.synchronize()
-        a = time.perf_counter()
-        for i in range(args.steps):
-            own[i % len(own)].commit()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - a
-        extra["own_stream_engines_groups_per_s"] = args.steps * G_BATCH / dt
-        extra["own_stream_engines_GBs"] = round(args.steps * G_BATCH * BYTES_PER_GROUP / dt / 1e9, 1)
-        if not np.array_equal(own[0].read_commit()[idx], want):
-            raise SystemExit("bench: own-stream result differs from the oracle")
-        for e in own:
-            e.close()
-    del mats
-
-    # on-box streaming ceiling: a device-to-device copy of 1 GiB, read + write bytes
-    if rank == 0:
-        a_t = torch.empty(1 << 28, dtype=torch.int32, device=dev)
-        b_t = torch.empty_like(a_t)
-        with torch.cuda.stream(stream):
-            for _ in range(3):
-                b_t.copy_(a_t)
-            ev4, ev5 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            ev4.record(stream)
-            for _ in range(10):
-                b_t.copy_(a_t)
-            ev5.record(stream)
-            ev5.synchronize()
-        extra["dtod_copy_GBs"] = round(10 * 2 * a_t.numel() * 4 / (ev4.elapsed_time(ev5) * 1e-3) / 1e9, 1)
-        del a_t, b_t
-
-    # the stateless entry point (what quorum.BatchCommittedIndex binds to): host planes in, host
-    # result out, engine created and destroyed per call — the PCIe-inclusive rate, never `value`
-    if rank == 0:
-        full = np.full(G_BATCH, (1 << VOTERS) - 1, dtype=np.uint8)
-        raft_amd.batch_committed_index(first_match, full, device=local_rank)
-        a = time.perf_counter()
-        for _ in range(3):
-            one = raft_amd.batch_committed_index(first_match, full, device=local_rank)
-        extra["oneshot_host_buffers_groups_per_s"] = 3 * G_BATCH / (time.perf_counter() - a)
-        if not np.array_equal(one[idx], want):
-            raise SystemExit("bench: one-shot result differs from the oracle")
-
-    # the one exchange step: changed (group, commit) pairs -> every rank.  An extra, measured after the
-    # timed region: a failure here is reported in the line, it does not take the headline with it.
-    from raft_amd import multigpu
+    # the one exchange step: changed (group, commit) pairs -> every rank, rafthip_commit_allgather over
+    # RCCL.  An extra, measured after the timed region: a failure here is reported in the line, it does
+    # not take the headline with it.
     try:
         with torch.cuda.stream(stream):
             e0 = engines[0]
@@ -278,33 +536,117 @@ def main():
             rng = np.random.default_rng(rank)
             recs["group"] = rng.integers(0, G_BATCH, size=len(recs))
             recs["slot"] = rng.integers(0, VOTERS, size=len(recs))
-            recs["index"] = np.uint64(1) << np.uint64(62)
-            e0.scatter_acks(recs)
-            multigpu.commit_changed_allgather(e0, rank * G_BATCH, cdev)  # untimed: first-use costs of torch / RCCL
-            recs["index"] = np.uint64(1) << np.uint64(63)
-            e0.scatter_acks(recs)
-            torch.cuda.synchronize()
-            a = time.perf_counter()
-            allp, n_changed = multigpu.commit_changed_allgather(e0, rank * G_BATCH, cdev)
-            torch.cuda.synchronize()
-            c = time.perf_counter()
+            if rehearse:
+                exch = lambda: multigpu.commit_changed_allgather(e0, rank * G_BATCH, cdev)  # noqa: E731
+                ranks_seen = world
+            else:
+                comm = multigpu.make_comm(e0, group_base=rank * G_BATCH)
+                ranks_seen = comm.nranks
+                gathered = torch.empty(2 * comm.nranks * comm.max_pairs_per_rank, dtype=torch.int64, device=dev)
+
+                def exch():
+                    _, counts, total = comm.commit_allgather(max_pairs=gathered.numel() // 2, dst=gathered.data_ptr())
+                    return gathered[:2 * total], int(counts[rank])
+            times = []
+            for k in range(4):  # the first exchange carries first-use costs and sizes its payload with a host wait
+                recs["index"] = (np.uint64(1) << np.uint64(62)) + np.uint64(k)
+                e0.scatter_acks(recs)
+                barrier()
+                a = time.perf_counter()
+                allp, n_changed = exch()
+                torch.cuda.synchronize()
+                times.append(time.perf_counter() - a)
+            if not rehearse:
+                allp = allp.cpu().numpy().view(raft_amd.PAIR_DTYPE)
+        (t_ex,) = max_over_ranks(min(times[1:]))
+        extra["rccl_ranks_seen"] = int(ranks_seen)
         extra["changed_pairs_rank0"] = int(n_changed)
-        extra["commit_changed_allgather_ms"] = round(1e3 * (c - a), 3)
+        extra["commit_changed_allgather_ms"] = round(1e3 * t_ex, 3)
+        extra["commit_changed_allgather_first_ms"] = round(1e3 * times[0], 3)
         extra["allgather_pairs_total"] = int(len(allp))
         if not (np.diff(allp["group"].astype(np.int64)) > 0).all():
             extra["commit_changed_allgather_error"] = "gathered pairs are not sorted by global group id"
+        if not rehearse:
+            comm.close()
+            del gathered
     except Exception as ex:
         extra["commit_changed_allgather_error"] = "%s: %s" % (type(ex).__name__, str(ex)[:300])
 
+    if not args.no_extras and world == 1:
+        # HIP-graph-amortised launch (SURVEY.md §8d caveat): one rotation over all batches, one shard per
+        # kernel, captured on the engine stream and replayed — the per-launch host cost is gone, what
+        # remains is the kernel plus the kernel-to-kernel boundary on the device
+        try:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=stream):
+                for e in engines:
+                    e.commit()
+            with torch.cuda.stream(stream):
+                for _ in range(5):
+                    graph.replay()
+                ev6, ev7 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                reps = max(1, 1200 // nb)
+                ev6.record(stream)
+                for _ in range(reps):
+                    graph.replay()
+                ev7.record(stream)
+                ev7.synchronize()
+            extra["hip_graph_avg_launch_us"] = round(1e3 * ev6.elapsed_time(ev7) / (reps * nb), 3)
+            del graph
+        except Exception as ex:  # capture is a measurement extra, never the headline
+            extra["hip_graph_avg_launch_us"] = None
+            extra["hip_graph_error"] = str(ex)[:200]
+
+        # the same rotation with every engine on its OWN stream and the single-engine entry point: passes
+        # over different engines are independent, so one pass's drain overlaps the next one's ramp-up
+        own = []
+        for m in mats:
+            e = raft_amd.Engine(G_BATCH, VOTERS, device=local_rank)
+            e.set_uniform_config(VOTERS)
+            e.upload_match(m)
+            own.append(e)
+        for i in range(200):
+            own[i % nb].commit()
+        torch.cuda.synchronize()
+        a = time.perf_counter()
+        for i in range(2000):
+            own[i % nb].commit()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - a
+        extra["own_stream_engines_groups_per_s"] = 2000 * G_BATCH / dt
+        extra["own_stream_engines_GBs"] = round(2000 * G_BATCH * BYTES_PER_GROUP / dt / 1e9, 1)
+        if not np.array_equal(own[0].read_commit()[idx], want):
+            raise SystemExit("bench: own-stream result differs from the oracle")
+        for e in own:
+            e.close()
+    del mats
+    for e in engines:
+        e.close()
+    engines = []
+
+    if not args.no_extras and world == 1:
+        # the two BASELINE configs that are defined across GPUs, whole on this one GPU
+        for name, runner in (("cfg3_joint_16M", run_cfg3), ("cfg5_scatter_commit_16M", run_cfg5)):
+            try:
+                info, e, _ = runner(raft_amd, torch, dev, local_rank, stream, 0, 1, 3)
+                e.close()
+                extra[name] = info
+            except Exception as ex:
+                extra[name] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
+            torch.cuda.empty_cache()
+
     if rank == 0:
-        total_groups = world * args.steps * G_BATCH
-        kernel_s = gpu_ms * 1e-3 / args.steps  # average launch duration over the timed region
-        achieved = BYTES_PER_GROUP * G_BATCH / kernel_s / 1e9
+        total_groups = world * K * G_BATCH
+        launch_s = gpu_ms * 1e-3 / n_launches          # average launch duration over the timed region
+        bytes_per_launch = BYTES_PER_GROUP * G_BATCH * K / n_launches
+        achieved = bytes_per_launch / launch_s / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_commit_uniform5.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                rec = json.load(open(pmc))
+                per_group = rec.get("hbm_bytes_per_group")
+                traffic = per_group * G_BATCH * K / n_launches if per_group else None
             except Exception:
                 traffic = None
         out = {
@@ -312,36 +654,36 @@ def main():
             "value": total_groups / wall,
             "unit": "groups/s",
             "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": 1e3 * wall / args.steps,
+            "steps": K,
+            "warmup": W,
+            "ms_per_step": 1e3 * wall / K,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "u64",
             "data": "synthetic",
             "config": {
-                "workload": "ProgressTracker.Committed, 2^20 groups x 5 voters per GPU per step, non-joint, "
-                            "dist A (bench_test.go:30-33), rotating over %d HBM-resident batches" % args.batches,
-                "groups_per_step_per_gpu": G_BATCH, "voters": VOTERS, "batches": args.batches,
+                "workload": "ProgressTracker.Committed, 2^20 groups x 5 voters per GPU per step, non-joint, dist A "
+                            "(bench_test.go:30-33), rotating over %d HBM-resident batches (shards); %d steps per "
+                            "rafthip_commit_many launch" % (nb, L),
+                "groups_per_step_per_gpu": G_BATCH, "voters": VOTERS, "batches": nb, "steps_per_launch": L,
                 "sharding": "group-id range, no data-path collective",
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "traffic_source": "profiles/pmc_commit_uniform5.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, per group)",
                 "frac_of_dtod_copy": (achieved / extra["dtod_copy_GBs"]) if extra.get("dtod_copy_GBs") else None,
-                "kernel": "k_commit_uniform<5, kStore>", "bytes_per_group": BYTES_PER_GROUP,
-                "avg_launch_us": kernel_s * 1e6,
+                "kernel": "k_commit_uniform_many<5>", "bytes_per_group": BYTES_PER_GROUP,
+                "bytes_per_launch": bytes_per_launch, "avg_launch_us": launch_s * 1e6, "launches": n_launches,
             },
             "extra": extra,
         }
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
             out["cpu_baseline"], _ = cpu_baseline(first_match)
             out["extra"].update(CPU_EXTRA)
-        print(json.dumps(out), flush=True)
+        emit(out)
 
-    for e in engines:
-        e.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

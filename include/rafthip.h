@@ -275,7 +275,9 @@ int rafthip_upload_ids(rafthip_engine *e, uint64_t first, uint64_t count, const 
 int rafthip_upload_term(rafthip_engine *e, uint64_t first, uint64_t count, const uint64_t *term);
 /* The pending ReadIndex request context of each group (readOnly.pendingReadIndex
  * key, read_only.go:29-37,68-76): ctx_len[g] bytes (0 = none pending, at most 8)
- * held little-endian in ctx[g] (byte i of the context = bits 8i..8i+7). */
+ * held little-endian in ctx[g] (byte i of the context = bits 8i..8i+7).  A
+ * length above 8 is RAFTHIP_EINVAL for host input; in device-resident input it
+ * is stored as "none pending" (such a host keeps that group's reads in Go). */
 int rafthip_upload_read_ctx(rafthip_engine *e, uint64_t first, uint64_t count, const uint64_t *ctx,
                             const uint8_t *ctx_len);
 /* The vote response type each group's campaign counts — stepCandidate's
@@ -375,6 +377,13 @@ int rafthip_progress_config(rafthip_engine *e, uint32_t max_inflight, uint64_t m
  * (Progress.ResetState, tracker/progress.go:102-107).  Match is rafthip_upload_match's. */
 int rafthip_upload_progress(rafthip_engine *e, uint64_t first, uint64_t count, const uint8_t *state,
                             const uint64_t *next, const uint64_t *pending, uint64_t src_stride);
+/* One new peer — Changer.initProgress, confchange/confchange.go:257-270: the row
+ * (slot, group) becomes {state, Next = next, PendingSnapshot = pending, empty
+ * Inflights}; the reference creates it as StateProbe with Next = max(LastIndex, 1).
+ * The group's other rows keep their state and Inflights (rafthip_upload_progress
+ * re-initialises whole groups).  Match is rafthip_upload_match's. */
+int rafthip_init_progress_row(rafthip_engine *e, uint64_t group, uint32_t slot, uint8_t state, uint64_t next,
+                              uint64_t pending);
 /* Any destination may be NULL.  infl_meta = Inflights.start | Inflights.count << 16,
  * infl_bytes = Inflights.bytes (tracker/inflights.go:28-40). */
 int rafthip_read_progress(rafthip_engine *e, uint64_t first, uint64_t count, uint8_t *state, uint64_t *next,

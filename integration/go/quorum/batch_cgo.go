@@ -8,13 +8,21 @@ import "C"
 
 import (
 	"fmt"
+	"runtime"
 	"unsafe"
 )
 
 // Device selects the GPU the stateless batch calls run on.
 var Device = 0
 
-func hipErr(rc C.int) error {
+// guarded runs one library call and, if it failed, fetches its error text.  The
+// text is thread-local in the library (rafthip_last_error), and a goroutine may
+// move to another OS thread between two cgo calls: the goroutine is locked to its
+// thread for the pair.
+func guarded(call func() C.int) error {
+	runtime.LockOSThread()
+	defer runtime.UnlockOSThread()
+	rc := call()
 	if rc == 0 {
 		return nil
 	}
@@ -28,13 +36,13 @@ func hipErr(rc C.int) error {
 // writes, so the result slices are filled in place.
 
 func hipBatchCommittedIndex(g, s int, match []uint64, in, out []byte, res []Index) error {
-	return hipErr(C.rafthip_batch_committed_index(C.int(Device), C.uint64_t(g), C.uint32_t(s),
+	return guarded(func() C.int { return C.rafthip_batch_committed_index(C.int(Device), C.uint64_t(g), C.uint32_t(s),
 		(*C.uint64_t)(unsafe.Pointer(&match[0])), unsafe.Pointer(&in[0]), unsafe.Pointer(&out[0]),
-		(*C.uint64_t)(unsafe.Pointer(&res[0]))))
+		(*C.uint64_t)(unsafe.Pointer(&res[0]))) })
 }
 
 func hipBatchVoteResult(g, s int, cells []uint8, in, out []byte, res []VoteResult) error {
-	return hipErr(C.rafthip_batch_vote_result(C.int(Device), C.uint64_t(g), C.uint32_t(s),
+	return guarded(func() C.int { return C.rafthip_batch_vote_result(C.int(Device), C.uint64_t(g), C.uint32_t(s),
 		(*C.uint8_t)(unsafe.Pointer(&cells[0])), unsafe.Pointer(&in[0]), unsafe.Pointer(&out[0]),
-		(*C.uint8_t)(unsafe.Pointer(&res[0]))))
+		(*C.uint8_t)(unsafe.Pointer(&res[0]))) })
 }

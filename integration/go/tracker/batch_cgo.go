@@ -15,6 +15,7 @@ import "C"
 
 import (
 	"fmt"
+	"runtime"
 	"unsafe"
 )
 
@@ -36,7 +37,14 @@ type Msg = C.rafthip_msg
 // CommitPair is a group whose commit index moved: the input of raft.maybeCommit.
 type CommitPair = C.rafthip_commit_pair
 
-func hipErr(rc C.int) error {
+// guarded runs one library call and, if it failed, fetches its error text.  The
+// text is thread-local in the library (rafthip_last_error), and a goroutine may
+// move to another OS thread between two cgo calls: the goroutine is locked to its
+// thread for the pair.
+func guarded(call func() C.int) error {
+	runtime.LockOSThread()
+	defer runtime.UnlockOSThread()
+	rc := call()
 	if rc == 0 {
 		return nil
 	}
@@ -50,11 +58,11 @@ func NewBatchEngine(device int, groups uint64, slots uint32, maxInflight uint32,
 	cfg := C.rafthip_config{struct_size: C.uint32_t(unsafe.Sizeof(C.rafthip_config{})), device: C.int32_t(device),
 		num_groups: C.uint64_t(groups), num_slots: C.uint32_t(slots)}
 	b := &BatchEngine{groups: groups, slots: slots}
-	if err := hipErr(C.rafthip_create(&cfg, &b.e)); err != nil {
+	if err := guarded(func() C.int { return C.rafthip_create(&cfg, &b.e) }); err != nil {
 		return nil, err
 	}
 	if maxInflight > 0 {
-		if err := hipErr(C.rafthip_progress_config(b.e, C.uint32_t(maxInflight), C.uint64_t(maxBytes))); err != nil {
+		if err := guarded(func() C.int { return C.rafthip_progress_config(b.e, C.uint32_t(maxInflight), C.uint64_t(maxBytes)) }); err != nil {
 			b.Close()
 			return nil, err
 		}
@@ -69,7 +77,7 @@ func (b *BatchEngine) Close() { C.rafthip_destroy(b.e); b.e = nil }
 func TickBuffer[T any](n int) ([]T, func(), error) {
 	var p unsafe.Pointer
 	var zero T
-	if err := hipErr(C.rafthip_host_alloc(&p, C.uint64_t(uintptr(n)*unsafe.Sizeof(zero)))); err != nil {
+	if err := guarded(func() C.int { return C.rafthip_host_alloc(&p, C.uint64_t(uintptr(n)*unsafe.Sizeof(zero))) }); err != nil {
 		return nil, nil, err
 	}
 	return unsafe.Slice((*T)(p), n), func() { C.rafthip_host_free(p) }, nil
@@ -77,8 +85,8 @@ func TickBuffer[T any](n int) ([]T, func(), error) {
 
 // SetConfig: raft.switchToConfig (raft.go:1949) for one group; masks are slot bitmasks.
 func (b *BatchEngine) SetConfig(group uint64, incoming, outgoing, learners uint64) error {
-	return hipErr(C.rafthip_upload_config(b.e, C.uint64_t(group), 1, unsafe.Pointer(&incoming), unsafe.Pointer(&outgoing),
-		unsafe.Pointer(&learners))) // little-endian: the low rafthip_mask_bytes() bytes are read
+	return guarded(func() C.int { return C.rafthip_upload_config(b.e, C.uint64_t(group), 1, unsafe.Pointer(&incoming), unsafe.Pointer(&outgoing),
+		unsafe.Pointer(&learners)) }) // little-endian: the low rafthip_mask_bytes() bytes are read
 }
 
 // ScatterAcks: Progress.MaybeUpdate's Match part for a tick's acks (progress.go:168-177).
@@ -86,7 +94,7 @@ func (b *BatchEngine) ScatterAcks(acks []Ack) error {
 	if len(acks) == 0 {
 		return nil
 	}
-	return hipErr(C.rafthip_scatter_acks(b.e, &acks[0], C.uint64_t(len(acks))))
+	return guarded(func() C.int { return C.rafthip_scatter_acks(b.e, &acks[0], C.uint64_t(len(acks))) })
 }
 
 // Step: stepLeader for a tick's responses and send records (raft.go:1333-1586).
@@ -96,8 +104,8 @@ func (b *BatchEngine) Step(msgs []Msg, aux []uint64, actions []uint8) error {
 	if len(msgs) == 0 {
 		return nil
 	}
-	return hipErr(C.rafthip_step_progress(b.e, &msgs[0], (*C.uint64_t)(unsafe.Pointer(&aux[0])), C.uint64_t(len(msgs)),
-		(*C.uint8_t)(unsafe.Pointer(&actions[0]))))
+	return guarded(func() C.int { return C.rafthip_step_progress(b.e, &msgs[0], (*C.uint64_t)(unsafe.Pointer(&aux[0])), C.uint64_t(len(msgs)),
+		(*C.uint8_t)(unsafe.Pointer(&actions[0]))) })
 }
 
 // StepWire: the same from serialized raftpb.Message payloads (message i =
@@ -106,9 +114,9 @@ func (b *BatchEngine) StepWire(bytes []byte, offsets []uint64, groups []uint32, 
 	if len(groups) == 0 {
 		return nil
 	}
-	return hipErr(C.rafthip_step_wire(b.e, (*C.uint8_t)(unsafe.Pointer(&bytes[0])), (*C.uint64_t)(unsafe.Pointer(&offsets[0])),
+	return guarded(func() C.int { return C.rafthip_step_wire(b.e, (*C.uint8_t)(unsafe.Pointer(&bytes[0])), (*C.uint64_t)(unsafe.Pointer(&offsets[0])),
 		(*C.uint32_t)(unsafe.Pointer(&groups[0])), C.uint64_t(len(groups)), nil, (*C.uint8_t)(unsafe.Pointer(&status[0])), nil,
-		(*C.uint8_t)(unsafe.Pointer(&actions[0]))))
+		(*C.uint8_t)(unsafe.Pointer(&actions[0]))) })
 }
 
 // Campaign: group starts (respType = MsgPreVoteResp or MsgVoteResp, stepCandidate's myVoteRespType,
@@ -116,20 +124,20 @@ func (b *BatchEngine) StepWire(bytes []byte, offsets []uint64, groups []uint32, 
 // the votes (raft.go:784 via reset, :893-896).  StepWire then records the group's vote responses.
 func (b *BatchEngine) Campaign(group uint64, respType uint8) error {
 	if respType != 0 {
-		if err := hipErr(C.rafthip_reset_votes(b.e, C.uint64_t(group), 1)); err != nil {
+		if err := guarded(func() C.int { return C.rafthip_reset_votes(b.e, C.uint64_t(group), 1) }); err != nil {
 			return err
 		}
 	}
-	return hipErr(C.rafthip_upload_campaign(b.e, C.uint64_t(group), 1, (*C.uint8_t)(unsafe.Pointer(&respType))))
+	return guarded(func() C.int { return C.rafthip_upload_campaign(b.e, C.uint64_t(group), 1, (*C.uint8_t)(unsafe.Pointer(&respType))) })
 }
 
 // TallyVotes: ProgressTracker.TallyVotes for every group (tracker/tracker.go:267-290); result[g] is
 // quorum.VoteResult (1 pending, 2 lost, 3 won).
 func (b *BatchEngine) TallyVotes(result []uint8) error {
-	if err := hipErr(C.rafthip_tally_votes(b.e)); err != nil {
+	if err := guarded(func() C.int { return C.rafthip_tally_votes(b.e) }); err != nil {
 		return err
 	}
-	return hipErr(C.rafthip_read_vote_result(b.e, 0, C.uint64_t(len(result)), (*C.uint8_t)(unsafe.Pointer(&result[0])), nil, nil))
+	return guarded(func() C.int { return C.rafthip_read_vote_result(b.e, 0, C.uint64_t(len(result)), (*C.uint8_t)(unsafe.Pointer(&result[0])), nil, nil) })
 }
 
 // MaybeCommit: raft.maybeCommit for every group (raft.go:755-758, log.go:447-456);
@@ -140,7 +148,7 @@ func (b *BatchEngine) MaybeCommit(pairs []CommitPair) (int, error) {
 	if len(pairs) > 0 {
 		p = &pairs[0]
 	}
-	err := hipErr(C.rafthip_commit_advance(b.e, p, C.uint64_t(len(pairs)), &n))
+	err := guarded(func() C.int { return C.rafthip_commit_advance(b.e, p, C.uint64_t(len(pairs)), &n) })
 	if int(n) > len(pairs) {
 		n = C.uint64_t(len(pairs))
 	}
@@ -150,23 +158,23 @@ func (b *BatchEngine) MaybeCommit(pairs []CommitPair) (int, error) {
 // CheckQuorum: the MsgCheckQuorum step for every group (raft.go:1231-1243);
 // active[g] == 0 means group g steps down.
 func (b *BatchEngine) CheckQuorum(active []uint8) error {
-	if err := hipErr(C.rafthip_check_quorum(b.e)); err != nil {
+	if err := guarded(func() C.int { return C.rafthip_check_quorum(b.e) }); err != nil {
 		return err
 	}
-	return hipErr(C.rafthip_read_quorum_active(b.e, 0, C.uint64_t(len(active)), (*C.uint8_t)(unsafe.Pointer(&active[0]))))
+	return guarded(func() C.int { return C.rafthip_read_quorum_active(b.e, 0, C.uint64_t(len(active)), (*C.uint8_t)(unsafe.Pointer(&active[0]))) })
 }
 
 // HeartbeatCommit: sendHeartbeat's commit per peer (raft.go:669-685), [slot][group].
 func (b *BatchEngine) HeartbeatCommit(dst []uint64) error {
-	return hipErr(C.rafthip_heartbeat_commit(b.e, 0, C.uint64_t(b.groups), (*C.uint64_t)(unsafe.Pointer(&dst[0])),
-		C.uint64_t(b.groups)))
+	return guarded(func() C.int { return C.rafthip_heartbeat_commit(b.e, 0, C.uint64_t(b.groups), (*C.uint64_t)(unsafe.Pointer(&dst[0])),
+		C.uint64_t(b.groups)) })
 }
 
 // Heartbeats: bcastHeartbeat as wire bytes (raft.go:698-716, Message.Marshal): the MsgHeartbeat to
 // slot s of group g is bytes[(s*groups+g)*72:][:lens[s*groups+g]]; length 0 = none to send.
 func (b *BatchEngine) Heartbeats(bytes, lens []uint8) error {
-	return hipErr(C.rafthip_emit_heartbeats(b.e, 0, C.uint64_t(b.groups), (*C.uint8_t)(unsafe.Pointer(&bytes[0])),
-		(*C.uint8_t)(unsafe.Pointer(&lens[0]))))
+	return guarded(func() C.int { return C.rafthip_emit_heartbeats(b.e, 0, C.uint64_t(b.groups), (*C.uint8_t)(unsafe.Pointer(&bytes[0])),
+		(*C.uint8_t)(unsafe.Pointer(&lens[0]))) })
 }
 
 // PlanAppends: bcastAppend as a plan (raft.go:689-696): plan[s*groups+g] is what maybeSendAppend(to, sendIfEmpty)
@@ -176,6 +184,66 @@ func (b *BatchEngine) PlanAppends(sendIfEmpty bool, plan []uint8, next []uint64)
 	if sendIfEmpty {
 		sie = 1
 	}
-	return hipErr(C.rafthip_plan_appends(b.e, 0, C.uint64_t(b.groups), sie, (*C.uint8_t)(unsafe.Pointer(&plan[0])),
-		(*C.uint64_t)(unsafe.Pointer(&next[0])), C.uint64_t(b.groups)))
+	return guarded(func() C.int { return C.rafthip_plan_appends(b.e, 0, C.uint64_t(b.groups), sie, (*C.uint8_t)(unsafe.Pointer(&plan[0])),
+		(*C.uint64_t)(unsafe.Pointer(&next[0])), C.uint64_t(b.groups)) })
+}
+
+// CommitMany: ProgressTracker.Committed for the shards several engines hold on ONE GPU, as one kernel
+// launch (rafthip_commit_many): the shards do not each pay a kernel boundary.
+func CommitMany(engines []*BatchEngine) error {
+	hs := make([]*C.rafthip_engine, len(engines))
+	for i, b := range engines {
+		hs[i] = b.e
+	}
+	return guarded(func() C.int { return C.rafthip_commit_many(&hs[0], C.uint32_t(len(hs))) })
+}
+
+// Exchange is one rank of the path's only collective (rafthip_comm_*): after the commit pass the
+// changed (or advanced) pairs of every GPU of the node are all-gathered over RCCL, so that the host
+// loop that feeds raft.maybeCommit (raft.go:755-758) and Ready's HardState.Commit (rawnode.go:141-156)
+// sees the whole node's set.  One Exchange per engine; ranks are goroutines locked to OS threads, one
+// per GPU, each calling Gather in the same tick.
+type Exchange struct {
+	c      *C.rafthip_comm
+	nranks int
+}
+
+// ExchangeID draws the communicator id on one rank; hand it to the others.
+func ExchangeID() (id C.rafthip_comm_id, err error) {
+	err = guarded(func() C.int { return C.rafthip_comm_unique_id(&id) })
+	return
+}
+
+// NewExchange is collective over the nranks ranks.  groupBase is the first global group id of this
+// engine's shard (shards are contiguous group-id ranges, ascending with rank).
+func NewExchange(b *BatchEngine, id C.rafthip_comm_id, rank, nranks int, groupBase uint64) (*Exchange, error) {
+	x := &Exchange{nranks: nranks}
+	err := guarded(func() C.int {
+		return C.rafthip_comm_create(b.e, &id, C.int(rank), C.int(nranks), C.uint64_t(groupBase), 0, &x.c)
+	})
+	if err != nil {
+		return nil, err
+	}
+	return x, nil
+}
+
+func (x *Exchange) Close() { C.rafthip_comm_destroy(x.c); x.c = nil }
+
+// Gather: raft.maybeCommit on this rank's engine (advance) or the plain changed-commit pass, then the
+// all-gather: pairs receives the pairs of ALL ranks with global group ids, sorted by group; counts[r]
+// is what rank r reported.
+func (x *Exchange) Gather(advance bool, pairs []CommitPair, counts []uint64) (int, error) {
+	var total C.uint64_t
+	adv := C.int(0)
+	if advance {
+		adv = 1
+	}
+	var p *CommitPair
+	if len(pairs) > 0 {
+		p = &pairs[0]
+	}
+	err := guarded(func() C.int {
+		return C.rafthip_commit_allgather(x.c, adv, p, C.uint64_t(len(pairs)), (*C.uint64_t)(unsafe.Pointer(&counts[0])), &total)
+	})
+	return int(total), err
 }

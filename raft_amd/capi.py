@@ -47,6 +47,7 @@ SYMBOLS = [
     "rafthip_emit_heartbeats", "rafthip_plan_appends", "rafthip_commit_changed_static",
     "rafthip_comm_unique_id", "rafthip_comm_create", "rafthip_comm_create_all", "rafthip_comm_destroy",
     "rafthip_comm_info", "rafthip_commit_allgather", "rafthip_commit_allgather_many", "rafthip_commit_many",
+    "rafthip_init_progress_row",
 ]
 COMM_ID_BYTES = 128
 MSG_VOTE_RESP, MSG_PRE_VOTE_RESP = 6, 18
@@ -174,6 +175,7 @@ def load_library():
         "rafthip_progress_config": (i32, [vp, u32, u64]),
         "rafthip_upload_progress": (i32, [vp, u64, u64, vp, vp, vp, u64]),
         "rafthip_read_progress": (i32, [vp, u64, u64, vp, vp, vp, vp, vp, u64]),
+        "rafthip_init_progress_row": (i32, [vp, u64, u32, C.c_uint8, u64, u64]),
         "rafthip_upload_inflights": (i32, [vp, u64, u64, vp, vp, vp, vp, u64]),
         "rafthip_read_inflights": (i32, [vp, u64, u64, vp, vp, u64]),
         "rafthip_upload_first_index": (i32, [vp, u64, u64, vp]),
@@ -447,6 +449,10 @@ class Engine:
         first, count = self._range(first, count)
         assert state.shape == (self.S, count) and next.shape == (self.S, count)
         _check(self._L.rafthip_upload_progress(self._h, first, count, _ptr(state), _ptr(next), _ptr(pending), count))
+
+    def init_progress_row(self, group, slot, state=STATE_PROBE, next=1, pending=0):
+        """Changer.initProgress for one new peer: the row alone is re-created, Inflights emptied."""
+        _check(self._L.rafthip_init_progress_row(self._h, group, slot, state, next, pending))
 
     def upload_inflights(self, infl_meta, infl_bytes, ring_index, ring_bytes, first=0, count=None):
         first, count = self._range(first, count)

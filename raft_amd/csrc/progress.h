@@ -290,7 +290,8 @@ __global__ __launch_bounds__(kBlock) void k_progress_apply(const Msg* __restrict
     const Vec<u64, 2> r0 = load_vec<u64, 2>(rw), r1 = load_vec<u64, 2>(rw + 2);
     if ((u32)(r1.v[1] >> 32) != i + 1) return;  // another event of this Progress exchanged later: it owns the list
 
-    // (links above n can only be leftovers of a call that failed between the two passes: treated as the end)
+    // (a call that fails between the two passes marks the engine; the next call clears every head word first, so
+    // no link of an earlier batch is ever met here; links above n are still treated as the end)
     u32 len = 0;
     for (u32 j = i + 1; j != 0 && j <= n && len <= kStepLimit; j = prev[j - 1]) ++len;
     if (len > kStepLimit) {  // all of them stay DEFERRED
@@ -492,6 +493,27 @@ __global__ __launch_bounds__(kBlock) void k_plan_appends(ProgPlanes pl, u64 firs
 // (Re)initialise records of groups [first, first+count): State / paused / Next /
 // PendingSnapshot from planes of row pitch `count`, fresh Inflights
 // (Progress.ResetState, progress.go:102-107).
+// Head words of every Progress record back to 0: run before a link pass when an earlier call failed
+// between its link and apply passes and may have left list heads behind (rafthip_engine::heads_dirty).
+__global__ __launch_bounds__(kBlock) void k_progress_clear_heads(ProgRec* __restrict__ rec, u64 cells) {
+    const u64 i = (u64)blockIdx.x * kBlock + threadIdx.x;
+    if (i < cells) rec[i].head = 0;
+}
+
+// One Progress row as confchange's initProgress leaves it (confchange/confchange.go:257-270): the given
+// State / Next / PendingSnapshot, an empty Inflights; every other row of the group untouched.
+__global__ void k_progress_init_row(ProgRec* __restrict__ rec, u64 stride, u64 group, u32 slot, u32 pstate, u64 next,
+                                    u64 pending) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    ProgRec r;
+    r.next = next;
+    r.pending = pending;
+    r.ibytes = 0;
+    r.meta = rec_meta(0, 0, pstate & 7u);
+    r.head = 0;
+    rec[(u64)slot * stride + group] = r;
+}
+
 __global__ __launch_bounds__(kBlock) void k_progress_pack(ProgRec* __restrict__ rec, u64 stride, u64 first, u64 count,
                                                           u32 S, const uint8_t* __restrict__ pstate,
                                                           const u64* __restrict__ next,

@@ -8,8 +8,15 @@
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <emmintrin.h>
+
+#include <atomic>
+#include <chrono>
+#include <initializer_list>
 #include <mutex>
 #include <new>
+#include <thread>
+#include <vector>
 
 #include "kernels.h"
 #include "progress.h"
@@ -170,6 +177,7 @@ struct rafthip_engine {
     bool zero_copy_pending = false;  // a kernel on the stream reads the caller's page-locked memory: wait before returning
 
     bool prog = false;
+    bool heads_dirty = false;  // a link pass ran without its apply pass: list heads may be left in the records
     ProgPlanes pp{};
     u64* first_index = nullptr; // raftLog.firstIndex() per group
 
@@ -1133,7 +1141,7 @@ int rafthip_upload_term(rafthip_engine* e, uint64_t first, uint64_t count, const
     if ((rc = device_view(e, term, count * 8, &tmp, &d_term))) return rc;
     hipLaunchKernelGGL(k_hdr_set_field, dim3((u32)((count + kBlock - 1) / kBlock)), dim3(kBlock), 0, e->stream,
                        static_cast<const u64*>(d_term), static_cast<const uint8_t*>(nullptr), (u64)count, H, kHdrTerm,
-                       0u, 0u, e->wire_hdr + first * H);
+                       0u, 0u, 0xFFu, e->wire_hdr + first * H);
     if ((rc = finish_and_free(e, tmp, nullptr))) return rc;
     e->stats.bytes_uploaded += count * 8;
     return RAFTHIP_OK;
@@ -1145,6 +1153,12 @@ int rafthip_upload_read_ctx(rafthip_engine* e, uint64_t first, uint64_t count, c
     if (rc) return rc;
     if (!ctx || !ctx_len) return fail(RAFTHIP_EINVAL, "ctx/ctx_len is NULL");
     DeviceGuard guard(e->device);
+    if (!is_device_ptr(ctx_len)) {  // a row holds 8 context bytes; device-resident lengths are clamped by the kernel
+        for (u64 g = 0; g < count; ++g)
+            if (ctx_len[g] > 8)
+                return fail(RAFTHIP_EINVAL, "ctx_len[%llu] = %u: a pending ReadIndex context of more than 8 bytes is not supported",
+                            (u64)g, (unsigned)ctx_len[g]);
+    }
     if ((rc = ensure_wire_hdr(e))) return rc;
     if (count == 0) return RAFTHIP_OK;
     const u32 H = wire_hdr_words(e->S);
@@ -1157,7 +1171,7 @@ int rafthip_upload_read_ctx(rafthip_engine* e, uint64_t first, uint64_t count, c
     }
     hipLaunchKernelGGL(k_hdr_set_field, dim3((u32)((count + kBlock - 1) / kBlock)), dim3(kBlock), 0, e->stream,
                        static_cast<const u64*>(d_ctx), static_cast<const uint8_t*>(d_len), (u64)count, H, kHdrCtx,
-                       kHdrCtxLen, 0u, e->wire_hdr + first * H);
+                       kHdrCtxLen, 0u, 8u, e->wire_hdr + first * H);
     if ((rc = finish_and_free(e, tmp, tmp8))) return rc;
     e->stats.bytes_uploaded += count * 9;
     return RAFTHIP_OK;
@@ -1190,7 +1204,7 @@ int rafthip_upload_campaign(rafthip_engine* e, uint64_t first, uint64_t count, c
     }
     hipLaunchKernelGGL(k_hdr_set_field, dim3((u32)((count + kBlock - 1) / kBlock)), dim3(kBlock), 0, e->stream,
                        static_cast<const u64*>(nullptr), static_cast<const uint8_t*>(d_type), (u64)count, H, 0u,
-                       kHdrCtxLen, kHdrCampaignShift, e->wire_hdr + first * H);
+                       kHdrCtxLen, kHdrCampaignShift, 0xFFu, e->wire_hdr + first * H);
     if ((rc = finish_and_free(e, tmp, nullptr))) return rc;
     if (resp_type) e->campaigning = true;
     e->stats.bytes_uploaded += resp_type ? count : 0;
@@ -1199,6 +1213,16 @@ int rafthip_upload_campaign(rafthip_engine* e, uint64_t first, uint64_t count, c
 
 static int progress_passes(rafthip_engine* e, const Msg* d_msgs, const u64* d_aux, uint64_t n, uint8_t* d_act,
                            bool linked);
+// Before a link pass: if an earlier call failed between its link and apply passes, zero every list head.
+static int clear_stale_heads(rafthip_engine* e) {
+    if (!e->heads_dirty || !e->pp.rec) return RAFTHIP_OK;
+    const u64 cells = (u64)e->S * e->stride;
+    hipLaunchKernelGGL(k_progress_clear_heads, dim3((u32)((cells + kBlock - 1) / kBlock)), dim3(kBlock), 0, e->stream,
+                       e->pp.rec, cells);
+    HIP_TRY(hipGetLastError());
+    e->heads_dirty = false;
+    return RAFTHIP_OK;
+}
 
 // Decode + classify n serialized messages; actions == NULL: step them as K7 does
 // (rafthip_ingest_wire); else hand the decoded records to the Progress stepper
@@ -1273,6 +1297,10 @@ static int wire_run(rafthip_engine* e, const uint8_t* bytes, const uint64_t* off
         d_prev = static_cast<u32*>(e->stage_buf[kStagePrev]);
     }
     HIP_TRY(hipMemsetAsync(e->d_wire_counts, 0, RAFTHIP_WIRE_STATUSES * sizeof(u64), e->stream));
+    if (to_progress) {
+        if ((rc = clear_stale_heads(e))) return rc;
+        e->heads_dirty = true;  // the decode kernel links; cleared once the apply pass is on the stream
+    }
     for (u64 off = 0; off < n; off += kMaxRecordsPerLaunch) {
         const u64 m = n - off < kMaxRecordsPerLaunch ? n - off : kMaxRecordsPerLaunch;
         const u32 blocks = (u32)((m + kWireBlock - 1) / kWireBlock);
@@ -1425,6 +1453,19 @@ int rafthip_upload_progress(rafthip_engine* e, uint64_t first, uint64_t count, c
     return RAFTHIP_OK;
 }
 
+int rafthip_init_progress_row(rafthip_engine* e, uint64_t group, uint32_t slot, uint8_t state, uint64_t next,
+                              uint64_t pending) {
+    int rc = need_progress(e);
+    if (rc || (rc = check_range(e, group, 1))) return rc;
+    if (slot >= e->S) return fail(RAFTHIP_EINVAL, "slot %u outside [0, %u)", slot, e->S);
+    if ((state & 3u) > RAFTHIP_STATE_SNAPSHOT) return fail(RAFTHIP_EINVAL, "state %u is not a tracker.StateType", state & 3u);
+    DeviceGuard guard(e->device);
+    hipLaunchKernelGGL(k_progress_init_row, dim3(1), dim3(64), 0, e->stream, e->pp.rec, e->stride, (u64)group, slot,
+                       (u32)state, (u64)next, (u64)pending);
+    HIP_TRY(hipGetLastError());
+    return RAFTHIP_OK;
+}
+
 int rafthip_read_progress(rafthip_engine* e, uint64_t first, uint64_t count, uint8_t* state, uint64_t* next,
                           uint64_t* pending, uint32_t* infl_meta, uint64_t* infl_bytes, uint64_t dst_stride) {
     int rc = need_progress(e);
@@ -1524,6 +1565,9 @@ static int progress_passes(rafthip_engine* e, const Msg* d_msgs, const u64* d_au
     u32* prev = static_cast<u32*>(e->stage_buf[kStagePrev]);
     const u32 blocks = (u32)((n + kBlock - 1) / kBlock);
     if (!linked) {
+        int rc2 = clear_stale_heads(e);
+        if (rc2) return rc2;
+        e->heads_dirty = true;  // until the apply pass is on the stream
         hipLaunchKernelGGL(k_progress_link, dim3(blocks), dim3(kBlock), 0, e->stream, d_msgs, (u32)n, e->G, e->S,
                            e->stride, e->pp.rec, prev, e->term_last, d_act);
         HIP_TRY(hipGetLastError());
@@ -1533,6 +1577,7 @@ static int progress_passes(rafthip_engine* e, const Msg* d_msgs, const u64* d_au
                        e->pp, static_cast<const u32*>(prev), e->active, e->acks, e->mbytes,
                        static_cast<const u64*>(e->term_last), static_cast<const u64*>(e->first_index), d_act);
     HIP_TRY(hipGetLastError());
+    e->heads_dirty = false;
     return RAFTHIP_OK;
 }
 
@@ -1976,15 +2021,8 @@ int rafthip_read_commit(rafthip_engine* e, uint64_t first, uint64_t count, uint6
     return RAFTHIP_OK;
 }
 
-int rafthip_tally_votes(rafthip_engine* e) {
-    if (!e) return fail(RAFTHIP_EINVAL, "engine is NULL");
-    DeviceGuard guard(e->device);
-    int rc;
-    if ((rc = ensure(e, e->votes, (size_t)e->S * e->stride))) return rc;
-    if ((rc = ensure(e, e->vote_result, e->stride))) return rc;
-    if ((rc = ensure(e, e->granted, e->stride))) return rc;
-    if ((rc = ensure(e, e->rejected, e->stride))) return rc;
-    if (e->uniform && e->uniform_voters == 0 && (rc = ensure_masks(e))) return rc;
+// The vote tally kernels over e's planes (votes, masks, vote_result set; granted / rejected may be NULL).
+static int launch_tally_votes(rafthip_engine* e) {
     const bool uni = e->uniform && e->uniform_voters > 0;
     hipStream_t st = e->stream;
     // A uniform config of <= 8 voters only needs its voter planes (the other rows
@@ -2027,6 +2065,18 @@ int rafthip_tally_votes(rafthip_engine* e) {
     HIP_TRY(hipGetLastError());
     e->stats.groups_evaluated += e->G;
     return RAFTHIP_OK;
+}
+
+int rafthip_tally_votes(rafthip_engine* e) {
+    if (!e) return fail(RAFTHIP_EINVAL, "engine is NULL");
+    DeviceGuard guard(e->device);
+    int rc;
+    if ((rc = ensure(e, e->votes, (size_t)e->S * e->stride))) return rc;
+    if ((rc = ensure(e, e->vote_result, e->stride))) return rc;
+    if ((rc = ensure(e, e->granted, e->stride))) return rc;
+    if ((rc = ensure(e, e->rejected, e->stride))) return rc;
+    if (e->uniform && e->uniform_voters == 0 && (rc = ensure_masks(e))) return rc;
+    return launch_tally_votes(e);
 }
 
 int rafthip_read_vote_result(rafthip_engine* e, uint64_t first, uint64_t count, uint8_t* result,
@@ -2478,10 +2528,281 @@ int rafthip_commit_allgather_many(rafthip_comm** comms, int n, int advance, raft
 
 // ---- stateless one-shot forms ---------------------------------------------
 
+// Host planes in, host result out, nothing resident between calls.  What bounds this form is the
+// PCIe link (48 B per group at 5 voters), so the work is arranged around it (tools/pin_probe.hip, on
+// the MI355X box: a pageable hipMemcpy moves 31 GB/s up and 18 GB/s down, page-locked memory 57 / 54,
+// two host threads copy pageable -> page-locked at 80 GB/s, and hipHostRegister of caller memory is
+// refused):
+//   - a context (stream, events, page-locked staging slots) is taken from a process-wide pool and
+//     returned after the call: no engine, no device allocation, no page-locking per call;
+//   - the batch is cut into chunks; helper threads copy chunk k+1 of the caller's planes into a
+//     staging slot while the kernel of chunk k reads its slot over the link itself (zero-copy: the
+//     transfer and the quorum arithmetic are one pass) and writes its results into a page-locked
+//     result slot; the calling thread copies finished result slots to the caller's buffer.
+// Device pointers take the resident path instead (an engine for the duration of the call).
+}  // extern "C"
+
+namespace {
+
+constexpr int kShotSlots = 4;
+constexpr size_t kShotChunkBytes = 4u << 20;  // staged input bytes per chunk
+constexpr int kShotCopiers = 2;
+
+struct ShotCtx {
+    int device = -1;
+    hipStream_t stream = nullptr;   // even chunks
+    hipStream_t stream2 = nullptr;  // odd chunks: a chunk's kernel ramps up over the link while its predecessor drains
+    hipEvent_t done[kShotSlots] = {};
+    char* in[kShotSlots] = {};   // page-locked staging, host address
+    char* out[kShotSlots] = {};
+    char* d_in[kShotSlots] = {};  // the same memory as the device addresses it
+    char* d_out[kShotSlots] = {};
+    size_t in_cap = 0, out_cap = 0;
+    void* d_zero = nullptr;  // device zeros: the outgoing half of a non-joint call
+    size_t zero_cap = 0;
+};
+
+std::mutex g_shot_mu;
+std::vector<ShotCtx*> g_shot_pool;
+
+// memcpy into a staging slot with streaming stores (dst 16-byte aligned): the next reader of these
+// bytes is the GPU over PCIe, not this core, so they should not be left dirty in its cache.
+void stage_copy(char* dst, const char* src, size_t n) {
+    if (getenv("RAFTHIP_SHOT_PLAIN_COPY") || (reinterpret_cast<uintptr_t>(dst) & 15)) {
+        memcpy(dst, src, n);
+        return;
+    }
+    size_t i = 0;
+    for (; i + 64 <= n; i += 64) {
+        const __m128i a = _mm_loadu_si128(reinterpret_cast<const __m128i*>(src + i));
+        const __m128i b = _mm_loadu_si128(reinterpret_cast<const __m128i*>(src + i + 16));
+        const __m128i c = _mm_loadu_si128(reinterpret_cast<const __m128i*>(src + i + 32));
+        const __m128i d = _mm_loadu_si128(reinterpret_cast<const __m128i*>(src + i + 48));
+        _mm_stream_si128(reinterpret_cast<__m128i*>(dst + i), a);
+        _mm_stream_si128(reinterpret_cast<__m128i*>(dst + i + 16), b);
+        _mm_stream_si128(reinterpret_cast<__m128i*>(dst + i + 32), c);
+        _mm_stream_si128(reinterpret_cast<__m128i*>(dst + i + 48), d);
+    }
+    if (i < n) memcpy(dst + i, src + i, n - i);
+    _mm_sfence();
+}
+
+void shot_release_buffers(ShotCtx* c) {
+    for (int k = 0; k < kShotSlots; ++k) {
+        if (c->in[k]) (void)hipHostFree(c->in[k]);
+        if (c->out[k]) (void)hipHostFree(c->out[k]);
+        c->in[k] = c->out[k] = c->d_in[k] = c->d_out[k] = nullptr;
+    }
+    c->in_cap = c->out_cap = 0;
+}
+
+// A context for `device` with staging slots of at least the given sizes (device current).
+int shot_acquire(int device, size_t in_bytes, size_t out_bytes, size_t zero_bytes, ShotCtx** out) {
+    ShotCtx* c = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_shot_mu);
+        for (size_t i = 0; i < g_shot_pool.size(); ++i)
+            if (g_shot_pool[i]->device == device) {
+                c = g_shot_pool[i];
+                g_shot_pool.erase(g_shot_pool.begin() + (long)i);
+                break;
+            }
+    }
+    if (!c) {
+        c = new (std::nothrow) ShotCtx();
+        if (!c) return fail(RAFTHIP_ENOMEM, "host allocation failed");
+        c->device = device;
+    }
+    *out = c;  // from here on the caller returns it with shot_return, also on failure
+    if (!c->stream) HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    if (!c->stream2) HIP_TRY(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    for (int k = 0; k < kShotSlots; ++k)
+        if (!c->done[k]) HIP_TRY(hipEventCreateWithFlags(&c->done[k], hipEventDisableTiming));
+    if (c->in_cap < in_bytes || c->out_cap < out_bytes) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream2));
+        shot_release_buffers(c);
+        for (int k = 0; k < kShotSlots; ++k) {
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->in[k]), in_bytes, hipHostMallocDefault));
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->out[k]), out_bytes, hipHostMallocDefault));
+            HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->d_in[k]), c->in[k], 0));
+            HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->d_out[k]), c->out[k], 0));
+        }
+        c->in_cap = in_bytes;
+        c->out_cap = out_bytes;
+    }
+    if (c->zero_cap < zero_bytes) {
+        if (c->d_zero) HIP_TRY(hipFree(c->d_zero));
+        c->d_zero = nullptr;
+        c->zero_cap = 0;
+        HIP_TRY(hipMalloc(&c->d_zero, zero_bytes));
+        HIP_TRY(hipMemsetAsync(c->d_zero, 0, zero_bytes, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));  // both streams read it
+        c->zero_cap = zero_bytes;
+    }
+    return RAFTHIP_OK;
+}
+
+void shot_return(ShotCtx* c) {
+    if (!c) return;
+    std::lock_guard<std::mutex> lock(g_shot_mu);
+    g_shot_pool.push_back(c);
+}
+
+// One-shot pass over host planes.  cell = bytes per plane element (8: Match, 1: vote cells),
+// res = bytes per result (8 / 1).  launch(view) runs the kernel over a chunk-sized engine view.
+template <typename Launch>
+int shot_run(int device, u64 G, u32 S, size_t cell, size_t res, const void* planes, const void* in_mask,
+             const void* out_mask, void* result, Launch launch) {
+    const size_t mb = (size_t)mask_bytes_for(S);
+    const size_t per_group = cell * S + 2 * mb;
+    size_t chunk_bytes = kShotChunkBytes;
+    int want_copiers = kShotCopiers;
+    if (const char* v = getenv("RAFTHIP_SHOT_CHUNK_BYTES")) chunk_bytes = (size_t)strtoull(v, nullptr, 0);  // tuning knobs
+    if (const char* v = getenv("RAFTHIP_SHOT_COPIERS")) want_copiers = atoi(v);
+    if (want_copiers < 1) want_copiers = 1;
+    if (want_copiers > 16) want_copiers = 16;
+    u64 chunk = kPlaneAlign;  // groups per full chunk = slot capacity; a multiple of the plane granule
+    while (chunk * 2 * per_group <= chunk_bytes && chunk < (1ull << 24)) chunk *= 2;
+    if (chunk > round_up(G, kPlaneAlign)) chunk = round_up(G, kPlaneAlign);
+    // Chunk table.  The first kernel cannot start before its chunk is staged, so the batch opens with
+    // two quarter chunks and two half chunks and only then runs at full chunks.
+    std::vector<u64> start;
+    const bool ramp = G >= 4 * chunk;  // a batch of a few chunks is not worth the extra launches
+    for (u64 g = 0, k = 0; g < G; ++k) {
+        start.push_back(g);
+        u64 len = !ramp ? chunk : k < 2 ? chunk / 4 : k < 4 ? chunk / 2 : chunk;
+        if (len < kPlaneAlign) len = kPlaneAlign;
+        g += len;
+    }
+    const u64 nchunks = start.size();
+    start.push_back(G);
+    const size_t planes_b = (size_t)chunk * cell * S, mask_b = (size_t)chunk * mb;
+    DeviceGuard guard(device);
+    if (!guard.ok) return fail(RAFTHIP_ENODEV, "hipSetDevice(%d) failed", device);
+    ShotCtx* c = nullptr;
+    int rc = shot_acquire(device, planes_b + 2 * mask_b, (size_t)chunk * res, out_mask ? 0 : mask_b, &c);
+    if (rc) {
+        shot_return(c);
+        return rc;
+    }
+    // Staging: chunk k goes to slot k % kShotSlots once chunk k - kShotSlots has been retired.  The
+    // calling thread stages chunk 0 itself (the helpers are still starting); helper threads take the
+    // following chunks in order.
+    std::atomic<u64> staged[kShotSlots];  // chunks staged into this slot so far
+    std::atomic<u64> retired{0};          // chunks whose results have left their slot
+    std::atomic<u64> next_chunk{1};
+    std::atomic<bool> abort{false};
+    for (auto& r : staged) r.store(0);
+    auto stage_chunk = [&](u64 k) {
+        const int slot = (int)(k % kShotSlots);
+        while (retired.load(std::memory_order_acquire) + kShotSlots <= k) {
+            if (abort.load()) return;
+            std::this_thread::yield();
+        }
+        const u64 g0 = start[k], cnt = start[k + 1] - g0;
+        char* dst = c->in[slot];
+        for (u32 s = 0; s < S; ++s)
+            stage_copy(dst + (size_t)s * chunk * cell, static_cast<const char*>(planes) + ((size_t)s * G + g0) * cell, cnt * cell);
+        stage_copy(dst + planes_b, static_cast<const char*>(in_mask) + g0 * mb, cnt * mb);
+        if (out_mask) stage_copy(dst + planes_b + mask_b, static_cast<const char*>(out_mask) + g0 * mb, cnt * mb);
+        staged[slot].fetch_add(1, std::memory_order_release);
+    };
+    const int ncopiers = nchunks >= 4 ? want_copiers : 0;  // a small batch is staged by the calling thread alone
+    std::vector<std::thread> copiers;
+    for (int t = 0; t < ncopiers; ++t)
+        copiers.emplace_back([&] {
+            for (;;) {
+                const u64 k = next_chunk.fetch_add(1);
+                if (k >= nchunks || abort.load()) return;
+                stage_chunk(k);
+            }
+        });
+    const bool trace = getenv("RAFTHIP_SHOT_TRACE") != nullptr;
+    double t_ready = 0, t_launch = 0, t_event = 0, t_out = 0;
+    auto tick = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_begin = tick();
+    auto retire = [&](u64 k) -> int {
+        const int slot = (int)(k % kShotSlots);
+        const double t0 = tick();
+        HIP_TRY(hipEventSynchronize(c->done[slot]));
+        const double t1 = tick();
+        const u64 g0 = start[k], cnt = start[k + 1] - g0;
+        memcpy(static_cast<char*>(result) + g0 * res, c->out[slot], cnt * res);
+        retired.store(k + 1, std::memory_order_release);
+        t_event += t1 - t0;
+        t_out += tick() - t1;
+        return RAFTHIP_OK;
+    };
+    for (u64 k = 0; k < nchunks && !rc; ++k) {
+        const int slot = (int)(k % kShotSlots);
+        const double t0 = tick();
+        if (k == 0 || !ncopiers) stage_chunk(k);
+        while (staged[slot].load(std::memory_order_acquire) < k / kShotSlots + 1) std::this_thread::yield();
+        const double t1 = tick();
+        t_ready += t1 - t0;
+        rafthip_engine view;  // a chunk-sized view over the staging slot: the kernels read it over the link
+        view.device = device;
+        view.G = start[k + 1] - start[k];
+        view.S = S;
+        view.stride = chunk;
+        view.mbytes = (int)mb;
+        view.stream = (k & 1) ? c->stream2 : c->stream;
+        view.uniform = false;
+        view.in_mask = c->d_in[slot] + planes_b;
+        view.out_mask = out_mask ? static_cast<void*>(c->d_in[slot] + planes_b + mask_b) : c->d_zero;
+        rc = launch(view, c->d_in[slot], c->d_out[slot]);
+        if (!rc) {
+            hipError_t err = hipEventRecord(c->done[slot], view.stream);
+            if (err != hipSuccess) rc = fail(RAFTHIP_EIO, "hipEventRecord: %s", hipGetErrorString(err));
+        }
+        t_launch += tick() - t1;
+        if (!rc && k >= 1) rc = retire(k - 1);  // while chunk k runs
+    }
+    if (!rc) rc = retire(nchunks - 1);
+    if (rc) abort.store(true);
+    for (auto& t : copiers) t.join();
+    if (trace)
+        fprintf(stderr, "shot: G %llu chunks %llu total %.0f us: wait-staged %.0f launch %.0f wait-gpu %.0f copy-out %.0f\n", (u64)G,
+                (u64)nchunks, (tick() - t_begin) * 1e6, t_ready * 1e6, t_launch * 1e6, t_event * 1e6, t_out * 1e6);
+    if (rc) {
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipStreamSynchronize(c->stream2);
+    }
+    shot_return(c);
+    return rc;
+}
+
+bool host_pointers(std::initializer_list<const void*> ps) {
+    for (const void* p : ps)
+        if (p && is_device_ptr(p)) return false;
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
 int rafthip_batch_committed_index(int device, uint64_t num_groups, uint32_t num_slots,
                                   const uint64_t* match, const void* in_mask, const void* out_mask,
                                   uint64_t* out) {
     if (!match || !out) return fail(RAFTHIP_EINVAL, "match/out is NULL");
+    if (!in_mask) return fail(RAFTHIP_EINVAL, "in_mask is NULL");
+    if (num_groups == 0) return fail(RAFTHIP_EINVAL, "num_groups must be >= 1");
+    if (num_slots == 0 || num_slots > RAFTHIP_MAX_SLOTS)
+        return fail(RAFTHIP_EINVAL, "num_slots %u outside [1, %u]", num_slots, RAFTHIP_MAX_SLOTS);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(RAFTHIP_ENODEV, "no HIP device available (this library has no CPU path)");
+    if (device < 0 || device >= ndev) return fail(RAFTHIP_ENODEV, "device %d outside [0, %d)", device, ndev);
+    if (host_pointers({match, in_mask, out_mask, out}))
+        return shot_run(device, num_groups, num_slots, 8, 8, match, in_mask, out_mask, out,
+                        [](rafthip_engine& view, char* d_in, char* d_out) {
+                            view.match = reinterpret_cast<u64*>(d_in);
+                            view.commit = reinterpret_cast<u64*>(d_out);
+                            u32 bg = 0;
+                            return launch_commit<kStore>(&view, &bg);
+                        });
     rafthip_engine* e = nullptr;
     int rc = oneshot_engine(device, num_groups, num_slots, in_mask, out_mask, &e);
     if (rc) return rc;
@@ -2499,6 +2820,21 @@ int rafthip_batch_vote_result(int device, uint64_t num_groups, uint32_t num_slot
                               const uint8_t* votes, const void* in_mask, const void* out_mask,
                               uint8_t* out) {
     if (!votes || !out) return fail(RAFTHIP_EINVAL, "votes/out is NULL");
+    if (!in_mask) return fail(RAFTHIP_EINVAL, "in_mask is NULL");
+    if (num_groups == 0) return fail(RAFTHIP_EINVAL, "num_groups must be >= 1");
+    if (num_slots == 0 || num_slots > RAFTHIP_MAX_SLOTS)
+        return fail(RAFTHIP_EINVAL, "num_slots %u outside [1, %u]", num_slots, RAFTHIP_MAX_SLOTS);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(RAFTHIP_ENODEV, "no HIP device available (this library has no CPU path)");
+    if (device < 0 || device >= ndev) return fail(RAFTHIP_ENODEV, "device %d outside [0, %d)", device, ndev);
+    if (host_pointers({votes, in_mask, out_mask, out}))
+        return shot_run(device, num_groups, num_slots, 1, 1, votes, in_mask, out_mask, out,
+                        [](rafthip_engine& view, char* d_in, char* d_out) {
+                            view.votes = reinterpret_cast<uint8_t*>(d_in);
+                            view.vote_result = reinterpret_cast<uint8_t*>(d_out);
+                            return launch_tally_votes(&view);  // granted / rejected NULL: not computed
+                        });
     rafthip_engine* e = nullptr;
     int rc = oneshot_engine(device, num_groups, num_slots, in_mask, out_mask, &e);
     if (rc) return rc;

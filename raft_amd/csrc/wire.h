@@ -402,6 +402,7 @@ __global__ __launch_bounds__(kBlock) void k_emit_heartbeats(
             term = row[kHdrTerm];
             ctx = row[kHdrCtx];
             ctx_len = (u32)(row[kHdrCtxLen] & 0xFFu);
+            if (ctx_len > 8) ctx_len = 0;  // never stored (k_hdr_set_field); the message slot holds 8 context bytes
             com = commit[g];
         }
     }
@@ -449,15 +450,20 @@ __global__ __launch_bounds__(kBlock) void k_hdr_set_ids(const u64* __restrict__ 
     for (u32 s = 0; s < S; ++s) hdr[g * H + kHdrIds + s] = src[(u64)s * count + g];
 }
 // One word (and optionally a byte-wide second field) per group -> its row.
+// A byte above max8 is stored as 0 and its word as 0: a ReadIndex context longer than the 8 bytes a row
+// holds is "nothing pending" (the host entry point rejects such a length; this guards device-resident input).
 __global__ __launch_bounds__(kBlock) void k_hdr_set_field(const u64* __restrict__ src, const uint8_t* __restrict__ src8,
                                                           u64 count, u32 H, u32 field, u32 field8, u32 shift8,
-                                                          u64* __restrict__ hdr) {
+                                                          u32 max8, u64* __restrict__ hdr) {
     const u64 g = (u64)blockIdx.x * kBlock + threadIdx.x;
     if (g >= count) return;
-    if (src) hdr[g * H + field] = src[g];
+    u32 b = src8 ? src8[g] : 0u;
+    const bool over = b > max8;
+    if (over) b = 0;
+    if (src) hdr[g * H + field] = over ? 0ull : src[g];
     if (src8) {  // one byte of word field8, at bit `shift8`
         u64& w = hdr[g * H + field8];
-        w = (w & ~((u64)0xFFu << shift8)) | ((u64)src8[g] << shift8);
+        w = (w & ~((u64)0xFFu << shift8)) | ((u64)b << shift8);
     }
 }
 

@@ -148,7 +148,9 @@ int main() {
             err = "no tracker";
         } else {
             if (cmd == "setconfig") {
-                rc = trk->SetConfig(u(1), ids(arg(t, "in")), ids(arg(t, "out")), ids(arg(t, "learners")));
+                const std::string li = arg(t, "last");  // Changer.LastIndex, for the Progress of new peers
+                rc = trk->SetConfig(u(1), ids(arg(t, "in")), ids(arg(t, "out")), ids(arg(t, "learners")),
+                                    li.empty() ? 0 : strtoull(li.c_str(), nullptr, 10));
             } else if (cmd == "reset") {
                 rc = trk->ResetProgress(u(1));
             } else if (cmd == "ack") {

@@ -104,7 +104,7 @@ int BatchProgressTracker::push_config(uint64_t group) {
 
 int BatchProgressTracker::SetConfig(uint64_t group, const quorum::MajorityConfig& incoming,
                                     const quorum::MajorityConfig& outgoing,
-                                    const quorum::MajorityConfig& learners) {
+                                    const quorum::MajorityConfig& learners, uint64_t last_index) {
     if (group >= G_) return fail(RAFTHIP_ERANGE, "group %llu outside [0, %llu)", (unsigned long long)group,
                                  (unsigned long long)G_);
     quorum::MajorityConfig all = incoming;
@@ -153,6 +153,7 @@ int BatchProgressTracker::SetConfig(uint64_t group, const quorum::MajorityConfig
         ids[s] = 0;
     }
     // New ids get a fresh Progress: Match 0, RecentActive true (confchange.go:257-270).
+    std::vector<uint32_t> fresh;  // slots that changed hands: their per-peer state must not survive
     for (uint64_t id : all) {
         bool have = false;
         for (uint32_t s = 0; s < S_; ++s) have |= ((used >> s) & 1ull) && ids[s] == id;
@@ -162,6 +163,7 @@ int BatchProgressTracker::SetConfig(uint64_t group, const quorum::MajorityConfig
         ids[s] = id;
         used |= 1ull << s;
         active |= 1ull << s;
+        fresh.push_back(s);
         auto sv = stray_votes_.find(group);
         if (sv != stray_votes_.end()) {
             auto it = sv->second.find(id);
@@ -190,6 +192,13 @@ int BatchProgressTracker::SetConfig(uint64_t group, const quorum::MajorityConfig
     touch(active_dirty_, group);
     touch(rdacks_dirty_, group);
     if (row_dirty && (rc = lib(rafthip_upload_match(e_, group, 1, row.data(), 1)))) return rc;
+    if (progress_) {
+        // The slot may have held another peer: {StateProbe, Next max(LastIndex, 1), empty Inflights} for the
+        // new one only (Changer.initProgress, confchange.go:257-270); the surviving peers keep theirs.
+        for (uint32_t s : fresh)
+            if ((rc = lib(rafthip_init_progress_row(e_, group, s, RAFTHIP_STATE_PROBE, last_index > 1 ? last_index : 1, 0))))
+                return rc;
+    }
     return push_config(group);
 }
 

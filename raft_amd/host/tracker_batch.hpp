@@ -48,8 +48,12 @@ class BatchProgressTracker {
     // voters of the outgoing half, confchange.go:297-304).  Ids that stay keep
     // their Progress; removed ids lose it; new ids start with Match 0 and
     // RecentActive true (confchange.go:257-270).
+    // With EnableProgress, a new id's row is also re-created the way Changer.initProgress
+    // does — StateProbe, Next = max(last_index, 1), empty Inflights — and the rows of the
+    // ids that stay are left alone (last_index = Changer.LastIndex, the leader's last index).
     int SetConfig(uint64_t group, const quorum::MajorityConfig& incoming,
-                  const quorum::MajorityConfig& outgoing, const quorum::MajorityConfig& learners);
+                  const quorum::MajorityConfig& outgoing, const quorum::MajorityConfig& learners,
+                  uint64_t last_index = 0);
 
     // raft.reset on a role change (raft.go:774-784): every Progress of the
     // group is re-created — Match 0, RecentActive false — and votes are reset.

@@ -444,3 +444,48 @@ def test_emit_heartbeats_on_the_reference_cases():
                 m.ParseFromString(out[s, 0, :lens[s, 0]].tobytes())
                 assert (m.type, m.to, getattr(m, "from"), m.term, m.commit) == (8, int(peer), c["leader"], c["term"], want), c["src"]
                 assert not m.HasField("context")
+
+
+def test_read_ctx_longer_than_a_row_holds_is_refused_or_dropped(oracle):
+    """A row holds 8 context bytes (include/rafthip.h).  Host input with ctx_len > 8: RAFTHIP_EINVAL, nothing stored.
+    Device-resident input: stored as "none pending" — no context in the heartbeats, no ReadIndex ack from a response
+    that shares the first 8 bytes."""
+    import torch
+    S, G = 3, 64
+    rng = np.random.default_rng(77)
+    ids = np.ascontiguousarray(np.tile(np.arange(1, S + 1, dtype=np.uint64)[:, None], (1, G)))
+    term = np.full(G, 2, dtype=np.uint64)
+    ctx = rng.integers(1, 1 << 62, size=G, dtype=np.uint64)
+    good = np.full(G, 8, dtype=np.uint8)
+    bad = good.copy()
+    bad[5] = 9
+    self_mask = np.ones(G, dtype=np.uint8)
+    match = rng.integers(0, 1 << 40, size=(S, G), dtype=np.uint64)
+    with raft_amd.Engine(G, S) as e:
+        e.upload_match(match)
+        e.upload_ids(ids)
+        e.upload_term(term)
+        e.upload_self(self_mask)
+        e.upload_read_ctx(ctx, good)
+        with pytest.raises(capi.RafthipError, match="more than 8 bytes"):
+            e.upload_read_ctx(ctx, bad)
+        hb, lens = e.emit_heartbeats()
+        want, want_len = oracle.bcast_heartbeat(match, e.read_commit(), ids, term, ctx, good, self_mask)
+        assert np.array_equal(lens, want_len) and np.array_equal(hb, want)  # the refused upload changed nothing
+        d_ctx = torch.from_numpy(ctx.view(np.int64)).to("cuda")
+        d_len = torch.from_numpy(bad).to("cuda")
+        e.upload_read_ctx(d_ctx.data_ptr(), d_len.data_ptr())
+        hb, lens = e.emit_heartbeats()
+        none5 = good.copy()
+        none5[5] = 0
+        ctx5 = ctx.copy()
+        ctx5[5] = 0
+        want, want_len = oracle.bcast_heartbeat(match, e.read_commit(), ids, term, ctx5, none5, self_mask)
+        assert np.array_equal(lens, want_len) and np.array_equal(hb, want)
+        # a heartbeat response carrying a 9-byte context whose first 8 bytes equal the refused one: no ack
+        e.upload_acks(np.zeros(G, dtype=np.uint8))
+        blob = oracle.message_marshal(type=9, to=1, frm=2, term=2, context=int(ctx[5]).to_bytes(8, "little") + b"\x01")
+        data = np.frombuffer(blob, dtype=np.uint8).copy()
+        offsets = np.array([0, len(blob)], dtype=np.uint64)
+        _, status, _ = e.ingest_wire(data, offsets, np.array([5], dtype=np.uint32))
+        assert status[0] == capi.WIRE_APPLIED and e.read_acks()[5] == 0

@@ -477,3 +477,32 @@ def test_tracker_bcast_heartbeat(oracle):
     want = [l for l in want if not l.endswith(" ok")]
     assert out[:len(want)] == want, [(a, b) for a, b in zip(out, want) if a != b][:3]
     assert len(out) == len(want) + 1 and out[-1].startswith("error "), out[-1]
+
+
+@pytest.mark.gpu
+def test_setconfig_reuses_a_slot_with_a_fresh_progress():
+    """A removed peer's slot goes to a new id: the new peer must start as Changer.initProgress creates it
+    (confchange/confchange.go:257-270: StateProbe, Match 0, Next = max(LastIndex, 1), empty Inflights) — not
+    with the removed peer's StateReplicate, Next and full Inflights — and the surviving peer keeps everything."""
+    from oracle import pyoracle as po
+    rep = po.STATE_NAMES["StateReplicate"]
+    script = ["tracker 4 3", "setconfig 2 in=1,2,3 out= learners=", "progress 2 0", "leader 2 1 1 20", "firstindex 2 1",
+              # peers 2 and 3 replicate at 10/11; both get two MsgApps in flight: Inflights full (cap 2)
+              "initprogress 2 1 rows=2:%d:10:11:0:0,3:%d:10:11:0:0" % (rep, rep)]
+    for peer in (2, 3):
+        script += ["ev 2 %d %d 11 0 1 100" % (peer, 0xF1), "ev 2 %d %d 12 0 1 100" % (peer, 0xF1)]
+    script += ["flushprogress", "progressof 2 2", "progressof 2 3",
+               # 3 leaves, 4 joins as a learner (takes 3's slot); the leader's last index is 20
+               "setconfig 2 in=1,2 out= learners=4 last=20", "progressof 2 4", "progressof 2 2", "plan 2 1"]
+    out = run_cli("\n".join(script) + "\n")
+    assert not [l for l in out if l.startswith("error") or l == "dropped"], out
+    views = [dict(kv.split("=") for kv in l.split()[3:]) for l in out if l.startswith("progressof")]
+    full2, full3, new4, kept2 = views
+    assert full2["state"] == full3["state"] == str(rep) and full2["full"] == full3["full"] == "1" and full3["next"] == "13"
+    assert (new4["state"], new4["match"], new4["next"], new4["full"], new4["paused"]) == ("0", "0", "20", "0", "0")
+    assert kept2 == full2  # the surviving peer is left alone
+    plan = [l for l in out if l.startswith("plan ")][0]
+    rows = {int(a): (int(b), int(c)) for a, b, c in (t.split(":") for t in plan.split()[2].split(","))}
+    # a probing, unpaused new learner is sent entries from Next = 20 (the log has them: last index 20); the full
+    # replicating peer is paused
+    assert rows[4] == (1, 20) and rows[2][0] == 0, plan

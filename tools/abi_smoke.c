@@ -135,6 +135,8 @@ int main(void) {
     for (size_t i = 0; i < (size_t)S * COUNT; i++) state[i] = (uint8_t)((state[i] % 3) | (state[i] & 4)), im[i] = 0, ib[i] = 0;
     OK(rafthip_upload_progress(e, FIRST, COUNT, state, next, pend, COUNT));
     OK(rafthip_upload_inflights(e, FIRST, COUNT, im, ib, ri, rb, COUNT));
+    OK(rafthip_init_progress_row(e, FIRST, S - 1, RAFTHIP_STATE_PROBE, 7, 0));
+    FAILS(rafthip_init_progress_row(e, FIRST, S, RAFTHIP_STATE_PROBE, 7, 0)); /* slot past the end */
     OK(rafthip_upload_first_index(e, FIRST, COUNT, com));
     OK(rafthip_step_progress(e, msgs, aux, n, act));
     OK(rafthip_step_progress(e, msgs, NULL, n, NULL));
