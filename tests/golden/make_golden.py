@@ -1,26 +1,33 @@
 #!/usr/bin/env python3
-"""Re-encode the reference's golden vectors for the quorum hot path as JSON.
+"""Re-encode the reference's golden vectors for the quorum hot path as JSON — mechanically.
 
 Run in the build container (needs /root/reference, read as TEXT only):
 
     python tests/golden/make_golden.py
 
-Writes tests/golden/quorum_datadriven.json (the 127 datadriven cases of
-quorum/testdata/{majority_commit,joint_commit,majority_vote,joint_vote}.txt)
-and tests/golden/tables.json (the small tables of TestCommit,
-TestLeaderAcknowledgeCommit, TestProgressUpdate and TestFindConflictByTerm,
-transcribed below with their file:line) and tests/golden/figure7.json (the
-leader's side of testdata/probe_and_replicate.txt: what it received, what it
-sent and what it committed, line by line).  Only inputs and expected outputs are kept: the expected
-value of a datadriven stanza is the LAST line of its output block
-(quorum/datadriven_test.go:213,222,234,242); `clean` records that the block
-holds no "<--" line, i.e. the harness's metamorphic self-checks
-(datadriven_test.go:175-219,239) all agreed in the reference.
+Writes, into tests/golden/:
+  quorum_datadriven.json  the 127 datadriven cases of quorum/testdata/{majority_commit,joint_commit,
+                          majority_vote,joint_vote}.txt
+  tables.json             the tables of TestCommit, TestLeaderAcknowledgeCommit, TestFindConflictByTerm and
+                          TestProgressUpdate, lifted from the Go table literals (golit.py)
+  progress_tables.json    every table and imperative case of tracker/progress_test.go and
+                          tracker/inflights_test.go, lifted the same way
+  figure7.json            the leader's side of testdata/probe_and_replicate.txt, line by line
+  transcript_facts.json   what the interaction transcripts print (Progress strings, messages, vote and
+                          quorum log lines) with line numbers: what the hand-reconstructed scenarios cite
+Nothing in these five files is typed by hand; tests/test_fixture_provenance.py regenerates them into a
+scratch directory whenever /root/reference is present and requires byte identity.  Only inputs and
+expected outputs are kept: the expected value of a datadriven stanza is the LAST line of its output block
+(quorum/datadriven_test.go:213,222,234,242); `clean` records that the block holds no "<--" line, i.e. the
+harness's metamorphic self-checks (datadriven_test.go:175-219,239) all agreed in the reference.
 """
 import json
 import os
 import re
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import golit  # noqa: E402
 
 REF = os.environ.get("RAFT_REFERENCE", "/root/reference")
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -163,86 +170,326 @@ def parse_leader_view(name, leader, start_marker):
             "votes": votes, "events": events}
 
 
-def main():
+# ---------------------------------------------------------------------------------------------
+# Tables lifted from the reference's Go tests (golit.py reads the literals; nothing is typed here)
+# ---------------------------------------------------------------------------------------------
+
+def _go(path):
+    return open(os.path.join(REF, path), encoding="utf-8").read()
+
+
+def _src(path, first, last):
+    return "%s:%d-%d" % (path, first, last)
+
+
+def _zero(rows, ints=(), bools=()):
+    for r in rows:
+        for k in ints:
+            if r.get(k) is None:
+                r[k] = 0
+        for k in bools:
+            if r.get(k) is None:
+                r[k] = False
+    return rows
+
+
+def make_tables():
+    out = {}
+    body, a, b = golit.func_source(_go("raft_test.go"), "TestCommit")
+    rows = golit.struct_table(body)
+    # Match per peer, log (index, term), leader term, expected raftLog.committed after maybeCommit
+    out["TestCommit"] = {"src": _src("raft_test.go", a, b),
+                         "rows": [{"matches": r["matches"], "logs": [[e["Index"], e["Term"]] for e in r["logs"]],
+                                   "smTerm": r["smTerm"], "w": r["w"]} for r in rows]}
+    body, a, b = golit.func_source(_go("raft_paper_test.go"), "TestLeaderAcknowledgeCommit")
+    rows = golit.struct_table(body)
+    # cluster size, the non-leader peers that accept the entry, whether the entry commits
+    out["TestLeaderAcknowledgeCommit"] = {
+        "src": _src("raft_paper_test.go", a, b),
+        "rows": [{"size": r["size"], "acceptors": sorted(k for k, v in (r["nonLeaderAcceptors"] or {}).items() if v),
+                  "wack": r["wack"]} for r in rows]}
+    body, a, b = golit.func_source(_go("log_test.go"), "TestFindConflictByTerm")
+    rows = golit.struct_table(body)
+    # ents(from, terms): ents[0] is the snapshot (index, term), the rest the log; want = the index
+    # findConflictByTerm(index, term) returns
+    for r in rows:
+        assert r["ents"]["call"] == "ents", r
+    out["TestFindConflictByTerm"] = {
+        "src": _src("log_test.go", a, b),
+        "rows": [{"from": r["ents"]["args"][0], "terms": r["ents"]["args"][1], "index": r["index"], "term": r["term"],
+                  "want": r["want"]} for r in rows]}
+    upd = progress_update_table()
+    out["TestProgressUpdate"] = {"src": upd["src"], "prevM": upd["prev_match"], "prevN": upd["prev_next"], "rows": upd["rows"]}
+    return out
+
+
+def _consts(body, names):
+    """`a, b := uint64(3), uint64(5)` / `match := uint64(1)` at the top of a test body -> {name: value}."""
+    env = {}
+    for text, _ in golit.statements(body):
+        m = re.match(r"^([\w, ]+) := (.*)$", text)
+        if not m:
+            continue
+        lhs = [x.strip() for x in m.group(1).split(",")]
+        if not set(lhs) <= set(names):
+            continue
+        vals = golit.parse_expr("[]x{" + m.group(2) + "}", env)
+        env.update(zip(lhs, vals))
+    assert set(env) == set(names), (env, names)
+    return env
+
+
+def progress_update_table():
+    body, a, b = golit.func_source(_go("tracker/progress_test.go"), "TestProgressUpdate")
+    env = _consts(body, ["prevM", "prevN"])
+    rows = golit.struct_table(body, env)
+    return {"src": _src("tracker/progress_test.go", a, b), "prev_match": env["prevM"], "prev_next": env["prevN"],
+            "rows": rows}
+
+
+def _progress_literal(d):
+    """&Progress{State: ..., Match: ...} -> the fields the fixtures use."""
+    known = {"State": "state", "Match": "match", "Next": "next", "PendingSnapshot": "pending",
+             "MsgAppFlowPaused": "paused"}
+    out = {}
+    for k, v in d.items():
+        if k == "Inflights":
+            assert v == {"call": "NewInflights", "args": [256, 0]}, v
+            continue
+        out[known[k]] = v
+    return out
+
+
+class _Walk:
+    """The statements of an imperative test body, consumed one pattern at a time; a statement no
+    pattern understands is an error — the generator never guesses."""
+
+    def __init__(self, path, func):
+        self.path = path
+        body, self.first, self.last = golit.func_source(_go(path), func)
+        self.stmts = golit.statements(body)
+        self.src = _src(path, self.first, self.last)
+
+    def run(self, patterns):
+        for text, _ in self.stmts:
+            for rx, fn in patterns:
+                m = re.match(rx, text)
+                if m:
+                    fn(m)
+                    break
+            else:
+                raise golit.GoSyntaxError("%s: statement not understood: %s" % (self.src, text))
+
+
+def make_progress_tables():
+    pt = "tracker/progress_test.go"
+    out = {"_comment": "Generated by make_golden.py from the reference's tracker tests: Go table literals and the "
+                       "statements of the imperative tests, read as text (golit.py).  No hand edits."}
+    body, a, b = golit.func_source(_go(pt), "TestProgressIsPaused")
+    out["is_paused"] = {"src": _src(pt, a, b), "rows": golit.struct_table(body)}
+
+    # TestProgressResume: p := &Progress{...}; calls; assert.False(t, p.MsgAppFlowPaused) after some of them
+    w = _Walk(pt, "TestProgressResume")
+    res = {"src": w.src, "steps": []}
+    w.run([
+        (r"^p := (&Progress\{.*\})$", lambda m: res.update(_progress_literal(golit.parse_expr(m.group(1))))),
+        (r"^p\.MaybeDecrTo\((\d+), (\d+)\)$",
+         lambda m: res["steps"].append({"op": "maybe_decr_to", "rejected": int(m.group(1)), "hint": int(m.group(2))})),
+        (r"^p\.MaybeUpdate\((\d+)\)$", lambda m: res["steps"].append({"op": "maybe_update", "n": int(m.group(1))})),
+        (r"^p\.MsgAppFlowPaused = true$", lambda m: res["steps"].append({"op": "set_paused"})),
+        (r"^assert\.False\(t, p\.MsgAppFlowPaused\)$", lambda m: res["steps"][-1].update(paused_after=False)),
+    ])
+    out["resume"] = res
+
+    body, a, b = golit.func_source(_go(pt), "TestProgressBecomeProbe")
+    env = _consts(body, ["match"])
+    rows = golit.struct_table(body, env)
+    out["become_probe"] = {"src": _src(pt, a, b),
+                           "rows": [dict({"pending": 0}, **_progress_literal(r["p"]), wnext=r["wnext"]) for r in rows]}
+
+    for func, key, call_rx, extra in (
+            ("TestProgressBecomeReplicate", "become_replicate", r"^p\.BecomeReplicate\(\)$", None),
+            ("TestProgressBecomeSnapshot", "become_snapshot", r"^p\.BecomeSnapshot\((\d+)\)$", "snapshoti")):
+        w = _Walk(pt, func)
+        rec = {"src": w.src}
+        want = {}
+
+        def called(m, rec=rec, extra=extra):
+            if extra:
+                rec[extra] = int(m.group(1))
+
+        def asserted(m, rec=rec, want=want):
+            env = {"p.Match": want.get("Match", rec.get("match"))}
+            want[m.group(2)] = golit.parse_expr(m.group(1), env)
+
+        w.run([
+            (r"^p := (&Progress\{.*\})$", lambda m, rec=rec: rec.update(_progress_literal(golit.parse_expr(m.group(1))))),
+            (call_rx, called),
+            (r"^assert\.Equal\(t, (.+), p\.(\w+)\)$", asserted),
+        ])
+        assert want["Match"] == rec["match"], (func, want)  # both tests assert that Match is untouched
+        if key == "become_replicate":
+            assert want["State"] == "StateReplicate"
+            rec["wnext"] = want["Next"]
+        else:
+            assert want["State"] == "StateSnapshot"
+            rec["wpending"] = want["PendingSnapshot"]
+        out[key] = rec
+
+    out["maybe_update"] = progress_update_table()
+    body, a, b = golit.func_source(_go(pt), "TestProgressMaybeDecr")
+    out["maybe_decr"] = {"src": _src(pt, a, b), "rows": golit.struct_table(body)}
+
+    it = "tracker/inflights_test.go"
+
+    def want_literal(d):
+        buf = d["buffer"]
+        assert buf["call"] == "inflightsBuffer" and len(buf["args"]) == 2, buf
+        return {"start": d.get("start", 0), "count": d.get("count", 0), "bytes": d.get("bytes", 0),
+                "index": buf["args"][0], "sizes": buf["args"][1]}, d["size"]
+
+    def walk_inflights(func):
+        """cases: {var: {"size", "start", "steps": [...]}}, in order of first appearance."""
+        w = _Walk(it, func)
+        cases, wants = {}, {}
+
+        def new_lit(m):
+            d = golit.parse_expr(m.group(2))
+            assert d["buffer"] == {"call": "make", "args": ["<type>", d["size"]]}, d
+            cases[m.group(1)] = {"size": d["size"], "start": d.get("start", 0), "steps": []}
+
+        def new_call(m):
+            assert int(m.group(3)) == 0  # no byte limit in these tests
+            cases[m.group(1)] = {"size": int(m.group(2)), "start": 0, "steps": []}
+
+        def add_loop(m):
+            assert m.group(1) == m.group(3) == m.group(5) == m.group(7) == m.group(8)  # the loop variable throughout
+            cases[m.group(6)]["steps"].append({"add": [int(m.group(2)), int(m.group(4))]})
+
+        def free(m):
+            cases[m.group(1)]["steps"].append({"free_le": int(m.group(2))})
+
+        def want(m):
+            wants[m.group(1)] = want_literal(golit.parse_expr(m.group(2)))
+
+        def equal(m):
+            lit, size = wants.pop(m.group(1))
+            c = cases[m.group(2)]
+            assert size == c["size"], (size, c)
+            assert "want" not in c["steps"][-1]
+            c["steps"][-1]["want"] = lit
+
+        w.run([
+            (r"^(\w+) := (&Inflights\{.*\})$", lambda m: want(m) if m.group(1).startswith("want") else new_lit(m)),
+            (r"^(\w+) := NewInflights\((\d+), (\d+)\)$", new_call),
+            (r"^for (\w+) := (\d+); (\w+) < (\d+); (\w+)\+\+ \{ (\w+)\.Add\(uint64\((\w+)\), uint64\(100\+(\w+)\)\) \}$", add_loop),
+            (r"^(\w+)\.FreeLE\((\d+)\)$", free),
+            (r"^require\.Equal\(t, (\w+), (\w+)\)$", equal),
+        ])
+        assert not wants
+        return w.src, list(cases.values())
+
+    src, cases = walk_inflights("TestInflightsAdd")
+    out["inflights_add"] = {"src": src, "cases": cases}
+    src, cases = walk_inflights("TestInflightFreeTo")
+    assert len(cases) == 1 and cases[0]["start"] == 0
+    out["inflights_free_to"] = {"src": src, "size": cases[0]["size"], "steps": cases[0]["steps"]}
+
+    body, a, b = golit.func_source(_go(it), "TestInflightsFull")
+    rows = _zero(golit.struct_table(body), ints=("size", "maxBytes", "fullAt", "freeLE", "againAt"))
+    out["inflights_full"] = {"src": _src(it, a, b),
+                             "_comment": "add (i, 100+i) from 0 until Full at fullAt; FreeLE(freeLE); add on until Full "
+                                         "again at againAt; one more Add panics", "rows": rows}
+
+    body, a, b = golit.func_source(_go(it), "TestInflightsReset")
+
+    def one(rx):
+        ms = re.findall(rx, body)
+        assert len(ms) == 1, (rx, ms)
+        return ms[0]
+
+    size, max_bytes = one(r"in := NewInflights\((\d+), (\d+)\)")
+    out["inflights_reset"] = {"src": _src(it, a, b), "size": int(size), "maxBytes": int(max_bytes),
+                              "epochs": int(one(r"for epoch := 0; epoch < (\d+); epoch\+\+")),
+                              "adds_per_epoch": int(one(r"for i := 0; i < (\d+); i\+\+")),
+                              "add_bytes": int(one(r"in\.Add\(index, (\d+)\)")),
+                              "keep": int(one(r"in\.FreeLE\(index - (\d+)\)"))}
+    assert int(one(r"require\.Equal\(t, (\d+), in\.Count\(\)\)\n\t\}")) == out["inflights_reset"]["keep"]
+    return out
+
+
+
+
+# ---------------------------------------------------------------------------------------------
+# Facts the interaction transcripts print, with their line numbers.  The scenario fixtures that
+# are reconstructed by hand (progress.json, scenarios.json: the transcripts run their set-up
+# with `log-level none`, so the event stream has to be read off the script) cite transcript
+# lines for every expected value; tests/test_fixture_provenance.py checks each citation
+# against these facts.
+# ---------------------------------------------------------------------------------------------
+
+TRANSCRIPTS = ["heartbeat_resp_recovers_from_probing.txt", "replicate_pause.txt", "snapshot_succeed_via_app_resp.txt",
+               "snapshot_succeed_via_app_resp_behind.txt", "checkquorum.txt", "prevote.txt",
+               "forget_leader_prevote_checkquorum.txt", "probe_and_replicate.txt"]
+PROGRESS_STR = re.compile(r"(?:^(\d+): )?(State(?:Probe|Replicate|Snapshot)) match=(\d+) next=(\d+)( learner)?( paused)?"
+                          r"(?: pendingSnap=(\d+))?( inactive)?(?: inflight=(\d+)(\[full\])?)?")
+MSG_LINE = re.compile(r"^\s*(\d+)->(\d+) (Msg\w+) Term:(\d+) Log:(\d+)/(\d+)(?: Commit:(\d+))?(?: Vote:(\d+))?"
+                      r"(?: Rejected \(Hint: (\d+)\))?(?: Entries:\[(.*)\])?")
+INFO_LINE = re.compile(r"^\s*(?:INFO|DEBUG|WARN) (\d+) (received Msg(?:Pre)?VoteResp (?:rejection )?from \d+ at term \d+"
+                       r"|has received \d+ Msg(?:Pre)?VoteResp votes and \d+ vote rejections"
+                       r"|stepped down to follower since quorum is not active"
+                       r"|became (?:leader|candidate|pre-candidate|follower) at term \d+)$")
+
+
+def transcript_facts(name):
+    lines = open(os.path.join(REF, "testdata", name), encoding="utf-8").read().split("\n")
+    prog, msgs, info = [], [], []
+    for n, ln in enumerate(lines, 1):
+        for m in PROGRESS_STR.finditer(ln):
+            prog.append({"line": n, "id": int(m.group(1)) if m.group(1) else None, "state": m.group(2),
+                         "match": int(m.group(3)), "next": int(m.group(4)), "learner": bool(m.group(5)),
+                         "paused": bool(m.group(6)), "pending": int(m.group(7) or 0), "inactive": bool(m.group(8)),
+                         "inflight": int(m.group(9) or 0), "full": bool(m.group(10))})
+        m = MSG_LINE.match(ln)
+        if m:
+            rec = {"line": n, "from": int(m.group(1)), "to": int(m.group(2)), "type": m.group(3), "term": int(m.group(4)),
+                   "log_term": int(m.group(5)), "index": int(m.group(6)), "commit": int(m.group(7) or 0),
+                   "reject": m.group(9) is not None, "entries": len(ENTRY.findall(m.group(10) or ""))}
+            if m.group(9) is not None:
+                rec["hint"] = int(m.group(9))
+            msgs.append(rec)
+        m = INFO_LINE.match(ln)
+        if m:
+            info.append({"line": n, "node": int(m.group(1)), "text": m.group(2)})
+    return {"progress": prog, "messages": msgs, "info": info}
+
+
+def write_json(path, obj):
+    with open(path, "w") as fh:
+        json.dump(obj, fh, indent=1)
+        fh.write("\n")
+
+
+def generate(out_dir):
+    """Every generated fixture into out_dir (tests/golden itself, or a scratch directory for the
+    regeneration check of tests/test_fixture_provenance.py)."""
     allc = []
     counts = {}
     for f in FILES:
         c = parse_file(f)
         counts[f] = len(c)
         allc.extend(c)
-    print(counts, "total", len(allc))
     assert counts == {"majority_commit.txt": 16, "joint_commit.txt": 50,
                       "majority_vote.txt": 22, "joint_vote.txt": 39}, counts
-    with open(os.path.join(HERE, "quorum_datadriven.json"), "w") as fh:
-        json.dump({"provenance": "quorum/testdata/*.txt @ reference, parsed by make_golden.py",
-                   "cases": allc}, fh, indent=1)
-
-    tables = {
-        # raft_test.go:1186-1203 — TestCommit: Match per peer, log (index,term), leader term,
-        # expected raftLog.committed after maybeCommit (initial committed = 0).
-        "TestCommit": {
-            "src": "raft_test.go:1186-1203",
-            "rows": [
-                {"matches": [1], "logs": [[1, 1]], "smTerm": 1, "w": 1},
-                {"matches": [1], "logs": [[1, 1]], "smTerm": 2, "w": 0},
-                {"matches": [2], "logs": [[1, 1], [2, 2]], "smTerm": 2, "w": 2},
-                {"matches": [1], "logs": [[1, 2]], "smTerm": 2, "w": 1},
-                {"matches": [2, 1, 1], "logs": [[1, 1], [2, 2]], "smTerm": 1, "w": 1},
-                {"matches": [2, 1, 1], "logs": [[1, 1], [2, 1]], "smTerm": 2, "w": 0},
-                {"matches": [2, 1, 2], "logs": [[1, 1], [2, 2]], "smTerm": 2, "w": 2},
-                {"matches": [2, 1, 2], "logs": [[1, 1], [2, 1]], "smTerm": 2, "w": 0},
-                {"matches": [2, 1, 1, 1], "logs": [[1, 1], [2, 2]], "smTerm": 1, "w": 1},
-                {"matches": [2, 1, 1, 1], "logs": [[1, 1], [2, 1]], "smTerm": 2, "w": 0},
-                {"matches": [2, 1, 1, 2], "logs": [[1, 1], [2, 2]], "smTerm": 1, "w": 1},
-                {"matches": [2, 1, 1, 2], "logs": [[1, 1], [2, 1]], "smTerm": 2, "w": 0},
-                {"matches": [2, 1, 2, 2], "logs": [[1, 1], [2, 2]], "smTerm": 2, "w": 2},
-                {"matches": [2, 1, 2, 2], "logs": [[1, 1], [2, 1]], "smTerm": 2, "w": 0},
-            ],
-        },
-        # raft_paper_test.go:482-490 — TestLeaderAcknowledgeCommit: cluster size, the
-        # non-leader peers that accept the entry, whether the entry commits.
-        "TestLeaderAcknowledgeCommit": {
-            "src": "raft_paper_test.go:482-490",
-            "rows": [
-                {"size": 1, "acceptors": [], "wack": True},
-                {"size": 3, "acceptors": [], "wack": False},
-                {"size": 3, "acceptors": [2], "wack": True},
-                {"size": 3, "acceptors": [2, 3], "wack": True},
-                {"size": 5, "acceptors": [], "wack": False},
-                {"size": 5, "acceptors": [2], "wack": False},
-                {"size": 5, "acceptors": [2, 3], "wack": True},
-                {"size": 5, "acceptors": [2, 3, 4], "wack": True},
-                {"size": 5, "acceptors": [2, 3, 4, 5], "wack": True},
-            ],
-        },
-        # log_test.go:66-95 — TestFindConflictByTerm: ents[0] is the snapshot (index, term), the rest
-        # the log; want = the index findConflictByTerm(index, term) returns (:106-107); its term is
-        # term(want) with out-of-bounds read as 0 (:108-110).
-        "TestFindConflictByTerm": {
-            "src": "log_test.go:66-95",
-            "rows": [{"from": f, "terms": t, "index": i, "term": tm, "want": w}
-                     for f, t in ((0, [0, 2, 2, 5, 5, 5]),) for i, tm, w in
-                     ((100, 2, 100), (5, 6, 5), (5, 5, 5), (5, 4, 2), (5, 2, 2), (5, 1, 0), (1, 2, 1), (1, 1, 0), (0, 0, 0))]
-                    + [{"from": f, "terms": t, "index": i, "term": tm, "want": w}
-                       for f, t in ((10, [3, 3, 3, 4, 4, 4]),) for i, tm, w in
-                       ((30, 3, 30), (14, 9, 14), (14, 4, 14), (14, 3, 12), (14, 2, 9), (11, 5, 11), (10, 5, 10),
-                        (10, 3, 10), (10, 2, 9), (9, 2, 9), (4, 2, 4), (0, 0, 0))],
-        },
-        # tracker/progress_test.go:124,132-135 — TestProgressUpdate: prev Match=3, Next=5.
-        "TestProgressUpdate": {
-            "src": "tracker/progress_test.go:124-135",
-            "prevM": 3, "prevN": 5,
-            "rows": [
-                {"update": 2, "wm": 3, "wn": 5, "wok": False},
-                {"update": 3, "wm": 3, "wn": 5, "wok": False},
-                {"update": 4, "wm": 4, "wn": 5, "wok": True},
-                {"update": 5, "wm": 5, "wn": 6, "wok": True},
-            ],
-        },
-    }
-    with open(os.path.join(HERE, "tables.json"), "w") as fh:
-        json.dump(tables, fh, indent=1)
-
+    write_json(os.path.join(out_dir, "quorum_datadriven.json"),
+               {"provenance": "quorum/testdata/*.txt @ reference, parsed by make_golden.py", "cases": allc})
+    write_json(os.path.join(out_dir, "tables.json"), make_tables())
+    write_json(os.path.join(out_dir, "progress_tables.json"), make_progress_tables())
+    write_json(os.path.join(out_dir, "transcript_facts.json"),
+               {"_doc": "What the reference's interaction transcripts (testdata/*.txt) print, by line: Progress strings "
+                        "(status rows carry the peer id), message lines, vote / quorum log lines.  Generated by "
+                        "make_golden.py; the hand-reconstructed scenarios cite these lines.",
+                "files": {name: transcript_facts(name) for name in TRANSCRIPTS}})
     fig7 = parse_leader_view("probe_and_replicate.txt", 1, "# Elect node 1 as leader and stabilize.")
     fig7["voters"] = [1, 2, 3, 4, 5, 6, 7]  # add-nodes 7 (probe_and_replicate.txt:34)
     fig7["_doc"] = ("The leader's side of the Raft-paper Figure 7 transcript: votes counted, entries appended, "
@@ -250,8 +497,16 @@ def main():
                     "`line` is the transcript line.  Parsed by make_golden.py, no hand edits.")
     kinds = [e["ev"] for e in fig7["events"]]
     assert kinds.count("recv") == 17 and kinds.count("commit") == 1 and len(fig7["votes"]) == 6, kinds
-    with open(os.path.join(HERE, "figure7.json"), "w") as fh:
-        json.dump(fig7, fh, indent=1)
+    write_json(os.path.join(out_dir, "figure7.json"), fig7)
+    return counts
+
+
+GENERATED = ["quorum_datadriven.json", "tables.json", "progress_tables.json", "transcript_facts.json", "figure7.json"]
+
+
+def main():
+    counts = generate(HERE)
+    print(counts, "-> ", ", ".join(GENERATED))
 
 
 if __name__ == "__main__":

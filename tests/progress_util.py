@@ -40,8 +40,13 @@ ACT = {"send_append": po.ACT_SEND_APPEND, "updated": po.ACT_UPDATED, "was_paused
 
 
 def load_fixture():
+    """The generated tables (progress_tables.json, lifted from the reference's Go tests by make_golden.py) and
+    the hand-reconstructed scenarios (progress.json) as one dict."""
+    with open(os.path.join(HERE, "golden", "progress_tables.json")) as fh:
+        fx = json.load(fh)
     with open(os.path.join(HERE, "golden", "progress.json")) as fh:
-        return json.load(fh)
+        fx["scenarios"] = json.load(fh)["scenarios"]
+    return fx
 
 
 def event(step, group=0, slot=0):
