@@ -22,6 +22,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK = 8000.0
+ATOMIC_RATE = 26.6e9  # scattered 8-byte atomics per second, measured: tools/scatter_probe.py, DESIGN.md §4
 
 
 def main():
@@ -41,7 +42,7 @@ def main():
     stream = torch.cuda.Stream(device=dev)
     rows = []
 
-    def timed(name, unit, units, bytes_per_unit, fn, setup=None, iters=None):
+    def timed(name, unit, units, bytes_per_unit, fn, setup=None, iters=None, atomics_per_unit=0):
         if args.only and args.only not in name:
             return
         iters = iters or args.iters
@@ -75,6 +76,9 @@ def main():
         row = {"kernel": name, "unit": unit, "units_per_launch": units, "bytes_per_unit": bytes_per_unit,
                "avg_launch_us": round(us, 2), "achieved_GBs": round(gbs, 1), "frac_of_8TBs": round(gbs / HBM_PEAK, 3),
                "units_per_s": units / us * 1e6}
+        if atomics_per_unit:  # bound by the rate of scattered memory-side atomics, not by bytes
+            row["bound"] = "atomic-rate"
+            row["frac_of_atomic_rate"] = round(atomics_per_unit * units / us * 1e6 / ATOMIC_RATE, 3)
         rows.append(row)
         print(json.dumps(row), flush=True)
 
@@ -94,14 +98,17 @@ def main():
                 tl = np.full(G, gu.U64MAX, dtype=np.uint64)
                 e.upload_term_range(tf, tl)
                 zero = np.zeros(G, dtype=np.uint64)
-                # commit_changed / commit_advance include the scan + pack kernels and a sync;
-                # the commit plane is reset before each launch so every group reports
-                timed("commit_changed, all groups change (K1+scan+pack)", "group", G, 8 * V + 16 + 32,
-                      lambda: e.commit_changed(max_pairs=0), setup=lambda: e.upload_commit(zero), iters=5)
-                timed("commit_changed, nothing changes (K1+scan+pack)", "group", G, 8 * V + 16,
-                      lambda: e.commit_changed(max_pairs=0), iters=5)
-                timed("commit_advance, nothing advances (K1 kAdvance+scan+pack)", "group", G, 8 * V + 32,
-                      lambda: e.commit_advance(max_pairs=0), iters=5)
+                d_pairs = torch.empty(2 * G, dtype=torch.int64, device=dev)
+                # commit_changed / commit_advance = the commit kernel in a reporting mode + k_pack_changed + the
+                # count read back; pairs land in device memory.  The commit plane is reset before each launch
+                # of the first row so every group reports: Match 8V + commit read 8 + written 8 + pair 16
+                timed("commit_changed, all groups change (K1 + k_pack_changed)", "group", G, 8 * V + 32,
+                      lambda: e.commit_report_into(d_pairs.data_ptr(), G), setup=lambda: e.upload_commit(zero), iters=5)
+                timed("commit_changed, nothing changes (K1 + k_pack_changed)", "group", G, 8 * V + 16,
+                      lambda: e.commit_report_into(d_pairs.data_ptr(), G), iters=5)
+                timed("commit_advance, nothing advances (K1 kAdvance + k_pack_changed)", "group", G, 8 * V + 32,
+                      lambda: e.commit_report_into(d_pairs.data_ptr(), G, advance=True), iters=5)
+                del d_pairs
                 timed("k_heartbeat_commit (K6)", "group", G, 16 * V + 8,
                       lambda: e.heartbeat_commit(download=False))
         del m
@@ -197,8 +204,10 @@ def main():
     with raft_amd.Engine(G, Sv, stream=stream.cuda_stream) as e:
         e.set_uniform_config(7)
         e.upload_match(m)
-        timed("k_scatter_acks, random cells (K5)", "ack", N, 24, lambda: e.scatter_acks(d_recs.data_ptr(), N))
-        timed("k_ingest_msgs, random cells (K7)", "msg", N, 24 + 4, lambda: e.ingest_msgs(d_msgs.data_ptr(), N))
+        timed("k_scatter_acks, random cells (K5)", "ack", N, 24, lambda: e.scatter_acks(d_recs.data_ptr(), N),
+              atomics_per_unit=1)
+        timed("k_ingest_msgs, random cells (K7)", "msg", N, 24 + 4, lambda: e.ingest_msgs(d_msgs.data_ptr(), N),
+              atomics_per_unit=1)
         timed("k_commit_uniform<7> over 9 slots (K1)", "group", G, 64, e.commit)
     # serialized responses (K8): same cells as the K7 stream, as gogo-protobuf bytes
     if not args.only or args.only in "k_ingest_wire, random cells (K8)":
@@ -221,7 +230,8 @@ def main():
             e.upload_term(term)
             e.upload_read_ctx(ctx, np.full(G, 8, dtype=np.uint8))
             timed("k_ingest_wire, %.1f B messages, random cells (K8)" % (len(data) / N), "msg", N, round(per_msg),
-                  lambda: e.ingest_wire(d_data, d_off, d_grp, n=N, want_msgs=False, want_status=False, want_counts=False))
+                  lambda: e.ingest_wire(d_data, d_off, d_grp, n=N, want_msgs=False, want_status=False, want_counts=False),
+                  atomics_per_unit=1)
         del data, offsets, d_data, d_off, d_grp
     # per-peer replication state (K9): sends + responses in stream order per Progress
     if not args.only or args.only in "k_progress_link + k_progress_apply (K9)":
@@ -243,7 +253,8 @@ def main():
             # record 16 + aux 8 + link 4+4 + action 1+1 + the 32-byte Progress record read and written
             # back + Match read (written only when it moves) = 106
             timed("k_progress_link + k_progress_apply, random cells (K9)", "event", N, 106,
-                  lambda: L.rafthip_step_progress(e._h, d_ev.data_ptr(), d_aux.data_ptr(), N, d_act.data_ptr()))
+                  lambda: L.rafthip_step_progress(e._h, d_ev.data_ptr(), d_aux.data_ptr(), N, d_act.data_ptr()),
+                  atomics_per_unit=1)
         del pl, ev, aux, d_ev, d_aux, d_act
     # dense tick through the Progress stepper (K9d): the same 4*G acks as a plane + heartbeat masks
     if not args.only or args.only in "k_progress_dense (K9d)":
@@ -332,14 +343,16 @@ def main():
     with raft_amd.Engine(G, Sv, stream=stream.cuda_stream) as e:
         e.set_uniform_config(7)
         e.upload_match(m)
-        timed("k_scatter_acks, group-sorted stream (K5)", "ack", N, 24, lambda: e.scatter_acks(d_recs.data_ptr(), N))
+        timed("k_scatter_acks, group-sorted stream (K5)", "ack", N, 24, lambda: e.scatter_acks(d_recs.data_ptr(), N),
+              atomics_per_unit=1)
 
-    print("\n| kernel | units/launch | B/unit | avg µs | GB/s | of 8 TB/s | units/s |")
-    print("|---|---|---|---|---|---|---|")
+    print("\n| kernel | units/launch | B/unit | avg µs | GB/s | of 8 TB/s | units/s | of the scattered-atomic rate (26.6e9/s) |")
+    print("|---|---|---|---|---|---|---|---|")
     for r in rows:
-        print("| %s | %d | %d | %.1f | %.0f | %.1f %% | %.3g |" % (
+        print("| %s | %d | %d | %.1f | %.0f | %.1f %% | %.3g | %s |" % (
             r["kernel"], r["units_per_launch"], r["bytes_per_unit"], r["avg_launch_us"], r["achieved_GBs"],
-            100 * r["frac_of_8TBs"], r["units_per_s"]))
+            100 * r["frac_of_8TBs"], r["units_per_s"],
+            ("%.0f %%" % (100 * r["frac_of_atomic_rate"])) if "frac_of_atomic_rate" in r else ""))
 
 
 if __name__ == "__main__":
