@@ -50,6 +50,7 @@ HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: 8.0 TB/s spec
 ATOMIC_RATE_PEAK = 26.6e9         # scattered 8-byte atomics/s, measured (tools/scatter_probe.py)
 CFG3_GROUPS = 1 << 24             # BASELINE configs[2]: 16M groups, joint, across the GPUs
 CFG5_GROUPS = 1 << 24             # BASELINE configs[4]: 7 voters + 2 learners, 4 acks per group
+EXCHANGE_TIMEOUT_S = 120          # the exchange extra may not hold the headline line back longer than this
 CPU_EXTRA = {}
 
 
@@ -528,51 +529,64 @@ def main():
 
     # the one exchange step: changed (group, commit) pairs -> every rank, rafthip_commit_allgather over
     # RCCL.  An extra, measured after the timed region: a failure here is reported in the line, it does
-    # not take the headline with it.
-    try:
-        with torch.cuda.stream(stream):
-            e0 = engines[0]
-            recs = np.zeros(G_BATCH // 8, dtype=raft_amd.ACK_DTYPE)  # acks touching 1/8 of the groups
-            rng = np.random.default_rng(rank)
-            recs["group"] = rng.integers(0, G_BATCH, size=len(recs))
-            recs["slot"] = rng.integers(0, VOTERS, size=len(recs))
-            if rehearse:
-                exch = lambda: multigpu.commit_changed_allgather(e0, rank * G_BATCH, cdev)  # noqa: E731
-                ranks_seen = world
-            else:
-                comm = multigpu.make_comm(e0, group_base=rank * G_BATCH)
-                ranks_seen = comm.nranks
-                gathered = torch.empty(2 * comm.nranks * comm.max_pairs_per_rank, dtype=torch.int64, device=dev)
+    # not take the headline with it — not even a collective that never returns: it runs on a helper
+    # thread, and a rank that has waited EXCHANGE_TIMEOUT_S for it reports that, prints the line and
+    # leaves the process without joining the thread.
+    import threading
+    exchange_hung = [False]
 
-                def exch():
-                    _, counts, total = comm.commit_allgather(max_pairs=gathered.numel() // 2, dst=gathered.data_ptr())
-                    return gathered[:2 * total], int(counts[rank])
-            times = []
-            for k in range(4):  # the first exchange carries first-use costs and sizes its payload with a host wait
-                recs["index"] = (np.uint64(1) << np.uint64(62)) + np.uint64(k)
-                e0.scatter_acks(recs)
-                barrier()
-                a = time.perf_counter()
-                allp, n_changed = exch()
-                torch.cuda.synchronize()
-                times.append(time.perf_counter() - a)
+    def exchange():
+        try:
+            torch.cuda.set_device(local_rank)
+            with torch.cuda.stream(stream):
+                e0 = engines[0]
+                recs = np.zeros(G_BATCH // 8, dtype=raft_amd.ACK_DTYPE)  # acks touching 1/8 of the groups
+                rng = np.random.default_rng(rank)
+                recs["group"] = rng.integers(0, G_BATCH, size=len(recs))
+                recs["slot"] = rng.integers(0, VOTERS, size=len(recs))
+                if rehearse:
+                    exch = lambda: multigpu.commit_changed_allgather(e0, rank * G_BATCH, cdev)  # noqa: E731
+                    ranks_seen = world
+                else:
+                    comm = multigpu.make_comm(e0, group_base=rank * G_BATCH)
+                    ranks_seen = comm.nranks
+                    gathered = torch.empty(2 * comm.nranks * comm.max_pairs_per_rank, dtype=torch.int64, device=dev)
+
+                    def exch():
+                        _, counts, total = comm.commit_allgather(max_pairs=gathered.numel() // 2, dst=gathered.data_ptr())
+                        return gathered[:2 * total], int(counts[rank])
+                times = []
+                for k in range(4):  # the first exchange carries first-use costs and sizes its payload with a host wait
+                    recs["index"] = (np.uint64(1) << np.uint64(62)) + np.uint64(k)
+                    e0.scatter_acks(recs)
+                    barrier()
+                    a = time.perf_counter()
+                    allp, n_changed = exch()
+                    torch.cuda.synchronize()
+                    times.append(time.perf_counter() - a)
+                if not rehearse:
+                    allp = allp.cpu().numpy().view(raft_amd.PAIR_DTYPE)
+            (t_ex,) = max_over_ranks(min(times[1:]))
+            extra["rccl_ranks_seen"] = int(ranks_seen)
+            extra["changed_pairs_rank0"] = int(n_changed)
+            extra["commit_changed_allgather_ms"] = round(1e3 * t_ex, 3)
+            extra["commit_changed_allgather_first_ms"] = round(1e3 * times[0], 3)
+            extra["allgather_pairs_total"] = int(len(allp))
+            if not (np.diff(allp["group"].astype(np.int64)) > 0).all():
+                extra["commit_changed_allgather_error"] = "gathered pairs are not sorted by global group id"
             if not rehearse:
-                allp = allp.cpu().numpy().view(raft_amd.PAIR_DTYPE)
-        (t_ex,) = max_over_ranks(min(times[1:]))
-        extra["rccl_ranks_seen"] = int(ranks_seen)
-        extra["changed_pairs_rank0"] = int(n_changed)
-        extra["commit_changed_allgather_ms"] = round(1e3 * t_ex, 3)
-        extra["commit_changed_allgather_first_ms"] = round(1e3 * times[0], 3)
-        extra["allgather_pairs_total"] = int(len(allp))
-        if not (np.diff(allp["group"].astype(np.int64)) > 0).all():
-            extra["commit_changed_allgather_error"] = "gathered pairs are not sorted by global group id"
-        if not rehearse:
-            comm.close()
-            del gathered
-    except Exception as ex:
-        extra["commit_changed_allgather_error"] = "%s: %s" % (type(ex).__name__, str(ex)[:300])
+                comm.close()
+        except Exception as ex:
+            extra["commit_changed_allgather_error"] = "%s: %s" % (type(ex).__name__, str(ex)[:300])
 
-    if not args.no_extras and world == 1:
+    th = threading.Thread(target=exchange, daemon=True)
+    th.start()
+    th.join(EXCHANGE_TIMEOUT_S)
+    if th.is_alive():
+        exchange_hung[0] = True
+        extra["commit_changed_allgather_error"] = "no return within %d s" % EXCHANGE_TIMEOUT_S
+
+    if not args.no_extras and world == 1 and not exchange_hung[0]:
         # HIP-graph-amortised launch (SURVEY.md §8d caveat): one rotation over all batches, one shard per
         # kernel, captured on the engine stream and replayed — the per-launch host cost is gone, what
         # remains is the kernel plus the kernel-to-kernel boundary on the device
@@ -620,11 +634,12 @@ def main():
         for e in own:
             e.close()
     del mats
-    for e in engines:
-        e.close()
-    engines = []
+    if not exchange_hung[0]:
+        for e in engines:
+            e.close()
+        engines = []
 
-    if not args.no_extras and world == 1:
+    if not args.no_extras and world == 1 and not exchange_hung[0]:
         # the two BASELINE configs that are defined across GPUs, whole on this one GPU
         for name, runner in (("cfg3_joint_16M", run_cfg3), ("cfg5_scatter_commit_16M", run_cfg5)):
             try:
@@ -684,6 +699,8 @@ def main():
             out["extra"].update(CPU_EXTRA)
         emit(out)
 
+    if exchange_hung[0]:
+        os._exit(0)  # a collective is stuck on the helper thread: no teardown can complete
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

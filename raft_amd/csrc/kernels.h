@@ -118,26 +118,6 @@ __device__ __forceinline__ void sort_asc_batcher(u64 (&v)[N]) {
     batcher_impl<N>(v, std::make_integer_sequence<int, Batcher<N>::n>{});
 }
 
-// The same network on (key, tag) pairs: the tag rides along with its key.
-template <int A, int B, int N>
-__device__ __forceinline__ void cex_tagged(u64 (&v)[N], u32 (&w)[N]) {
-    const u64 x = v[A], y = v[B];
-    const u32 p = w[A], q = w[B];
-    const bool lt = x < y;
-    v[A] = lt ? x : y;
-    v[B] = lt ? y : x;
-    w[A] = lt ? p : q;
-    w[B] = lt ? q : p;
-}
-template <int N, int... K>
-__device__ __forceinline__ void batcher_tagged_impl(u64 (&v)[N], u32 (&w)[N], std::integer_sequence<int, K...>) {
-    (cex_tagged<Batcher<N>::list.ce[K].a, Batcher<N>::list.ce[K].b, N>(v, w), ...);
-}
-template <int N>
-__device__ __forceinline__ void sort_asc_batcher_tagged(u64 (&v)[N], u32 (&w)[N]) {
-    batcher_tagged_impl<N>(v, w, std::make_integer_sequence<int, Batcher<N>::n>{});
-}
-
 // Minimal networks up to 8 keys, Batcher's above.
 template <int N>
 __device__ __forceinline__ void sort_keys(u64 (&v)[N]) {
@@ -177,6 +157,30 @@ __device__ __forceinline__ u64 committed_masked(const u64 (&v)[S], u32 m) {
     return m == 0 ? kU64Max : r;
 }
 
+// JointConfig.CommittedIndex from ONE sort, for keys below 2^62 (every real log index is): the key
+// moves up two bits and carries "member of the incoming half" / "of the outgoing half" in the two
+// bits it vacates, so the membership rides through the plain u64 network for free; after the sort a
+// scan from the largest key down counts members per half and picks each half's q-th largest
+// (quorum/joint.go:49-56 over quorum/majority.go:126-172).  Keys of slots in neither half are 0.
+// An empty half is never hit and yields MaxUint64, the identity of min.  The caller checks the 2^62
+// bound for the whole wavefront and takes another form otherwise (bit-exact either way).
+template <int N>
+__device__ __forceinline__ u64 joint_from_packed_batcher(u64 (&a)[N], u32 q0, u32 q1) {
+    sort_asc_batcher<N>(a);
+    // the selected entries stay packed until the end (one shift per half, not one per key)
+    u32 c0 = 0, c1 = 0;
+    u64 p0 = 0, p1 = 0;  // packed entries carry a non-zero tag: 0 = "no member reached the quorum-th place"
+#pragma unroll
+    for (int i = N - 1; i >= 0; --i) {
+        const u32 t = (u32)a[i] & 3u, in0 = t & 1u, in1 = t >> 1;
+        c0 += in0;
+        c1 += in1;
+        p0 = (in0 != 0 && c0 == q0) ? a[i] : p0;
+        p1 = (in1 != 0 && c1 == q1) ? a[i] : p1;
+    }
+    const u64 r0 = p0 ? (p0 >> 2) : kU64Max, r1 = p1 ? (p1 >> 2) : kU64Max;
+    return r0 < r1 ? r0 : r1;
+}
 // ---------------------------------------------------------------------------
 // Launch shape of the lane-per-group commit kernels (K1/K2).  A workgroup of
 // kCommitBlock lanes covers a tile of kTileGroups consecutive groups as kCH
@@ -405,6 +409,9 @@ __global__ __launch_bounds__(BLOCK) void k_commit_masked(const u64* __restrict__
     // Joint configs are transient (confchange.go:51-126); when no lane of the
     // wavefront holds one, the outgoing half is skipped for the whole wave.
     const bool wave_joint = __any(any_out);
+    // (Both halves from one sort with the membership in the key's low bits — regs_joint_packed — was tried
+    // here as well: no gain at 9..16 slots, where the two sorts hide behind the loads, and at <= 8 slots the
+    // extra code cost two waves per SIMD of occupancy.  Measured, not kept: profiles/r02_b_kernels.md.)
     Vec<u64, 2> res[CH];
 #pragma unroll
     for (int c = 0; c < CH; ++c)
@@ -500,36 +507,59 @@ __device__ __forceinline__ u64 regs_half(const u64* __restrict__ match, u64 stri
 
 // 48 / 64 keys: ask for 3 waves per SIMD (<= 168 VGPRs); left alone the
 // compiler takes 186 and drops to 2 (measured 632 -> 576 us at 2^22 x 64).
-// Both halves of a joint config from ONE sort: every key carries two tag bits
-// (member of the incoming / of the outgoing half); after the sort a scan from the
-// largest key down counts members per half and picks each half's q-th largest.
-// A tagged compare-exchange costs 7 operations against 5, so this is 1.4 sorts'
-// worth of work instead of the 2 sorts (and second key load) of zeroing the
-// non-members per half.
+// Both halves of a joint config from ONE plain sort: joint_from_packed's tags in
+// the two low bits of the shifted key.  (Round 1 carried the tags in a second
+// register per key: 7 operations per compare-exchange against 5, and above 32
+// keys the tag registers spilled, so those waves sorted twice and re-read the
+// keys: 977 us against 547 us non-joint at 2^22 x 64.)  Returns false — wave-
+// uniformly — when some member key is 2^62 or more; the caller then sorts per half.
 template <int N>
-__device__ __forceinline__ u64 regs_joint(const u64* __restrict__ match, u64 stride, int S, u64 m0, u64 m1) {
+__device__ __forceinline__ bool regs_joint_packed(const u64* __restrict__ match, u64 stride, int S, u64 m0, u64 m1,
+                                                  u64& out) {
     u64 a[N];
-    u32 tag[N];
     const u64* base = match + (u64)blockIdx.x * kBlock;
     const u32 t = threadIdx.x;
+    u64 top = 0;
 #pragma unroll
     for (int s = 0; s < N; ++s) {
         const u64* p = base + (u64)(s < S ? s : 0) * stride;  // rows >= S: re-read row 0, tag 0 (masks have no bit there)
         asm volatile("" : "+s"(p));
-        a[s] = __builtin_nontemporal_load(p + t);
-        tag[s] = (u32)((m0 >> s) & 1ull) | ((u32)((m1 >> s) & 1ull) << 1);
+        const u64 v = __builtin_nontemporal_load(p + t);
+        const u64 tag = ((m0 >> s) & 1ull) | (((m1 >> s) & 1ull) << 1);
+        const u64 key = v & (0ull - (u64)(tag != 0));
+        top |= key;
+        a[s] = (key << 2) | tag;
     }
-    sort_asc_batcher_tagged<N>(a, tag);
+    // the bound is tested AFTER the sort: a branch where every key is live costs a hundred spilled registers;
+    // a wave that fails it (no real log does) has sorted in vain
+    out = joint_from_packed_batcher<N>(a, (u32)__popcll(m0) / 2 + 1, (u32)__popcll(m1) / 2 + 1);
+    return __all((top >> 62) == 0);
+}
+
+// A joint wave with member keys of 2^62 or more (no real log index is): both halves by counting, in
+// rolled loops that hold no key array — the q-th largest member x of a half is the member with
+// #(members > x) < q <= #(members >= x).  S*S loads per lane, all cache hits; slow and never taken in
+// practice, but the kernel stays bit-exact for every u64 (and keeps no second sorting network alive
+// beside the one-sort path, which cost 100 spilled registers).
+__device__ __forceinline__ u64 joint_by_counting(const u64* __restrict__ match, u64 stride, int S, u64 g, u64 m0, u64 m1) {
     const u32 q0 = (u32)__popcll(m0) / 2 + 1, q1 = (u32)__popcll(m1) / 2 + 1;
-    u32 c0 = 0, c1 = 0;
-    u64 r0 = kU64Max, r1 = kU64Max;  // an empty half is never hit: MaxUint64, the identity of min
-#pragma unroll
-    for (int i = N - 1; i >= 0; --i) {
-        const u32 in0 = tag[i] & 1u, in1 = tag[i] >> 1;
-        c0 += in0;
-        c1 += in1;
-        r0 = (in0 != 0 && c0 == q0) ? a[i] : r0;
-        r1 = (in1 != 0 && c1 == q1) ? a[i] : r1;
+    u64 r0 = kU64Max, r1 = kU64Max;  // an empty half: MaxUint64, the identity of min
+#pragma unroll 1
+    for (int s = 0; s < S; ++s) {
+        if (!(((m0 | m1) >> s) & 1ull)) continue;
+        const u64 x = match[(u64)s * stride + g];
+        u32 gt0 = 0, ge0 = 0, gt1 = 0, ge1 = 0;
+#pragma unroll 1
+        for (int t = 0; t < S; ++t) {
+            const u64 y = match[(u64)t * stride + g];
+            const u32 in0 = (u32)((m0 >> t) & 1ull), in1 = (u32)((m1 >> t) & 1ull);
+            gt0 += in0 & (u32)(y > x);
+            ge0 += in0 & (u32)(y >= x);
+            gt1 += in1 & (u32)(y > x);
+            ge1 += in1 & (u32)(y >= x);
+        }
+        if (((m0 >> s) & 1ull) && gt0 < q0 && q0 <= ge0) r0 = x;
+        if (((m1 >> s) & 1ull) && gt1 < q1 && q1 <= ge1) r1 = x;
     }
     return r0 < r1 ? r0 : r1;
 }
@@ -556,21 +586,10 @@ __global__ __launch_bounds__(kBlock, (N > 32 ? 3 : 1)) void k_commit_regs(const 
     }
     u64 res;
     if (__any(m1 != 0)) {
-        if constexpr (N <= 32) {
-            // Joint wave: one tagged sort serves both halves (regs_joint).
-            res = regs_joint<N>(match, stride, S, m0, m1);
-        } else {
-            // Above 32 keys the tags do not fit the register budget of 3 waves per SIMD
-            // (they spill: 4.5 ms instead of 1 ms at 64 keys): one rolled loop over the
-            // two halves, keys re-loaded per half (the second read hits L2).  An empty
-            // half yields MaxUint64, the identity of min.
-            res = kU64Max;
-#pragma unroll 1
-            for (int h = 0; h < 2; ++h) {
-                const u64 r = regs_half<N, false>(match, stride, S, h ? m1 : m0);
-                res = r < res ? r : res;
-            }
-        }
+        // Joint wave: one sort serves both halves when every member key is below 2^62
+        // (regs_joint_packed); else one rolled loop over the two halves, keys re-loaded per
+        // half (the second read hits L2).  An empty half yields MaxUint64, the identity of min.
+        if (!regs_joint_packed<N>(match, stride, S, m0, m1, res)) res = joint_by_counting(match, stride, S, g, m0, m1);
     } else {
         res = regs_half<N, true>(match, stride, S, m0);
     }

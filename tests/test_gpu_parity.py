@@ -527,3 +527,33 @@ def test_two_engines_from_two_threads(oracle):
     for t in ts:
         t.join()
     assert not errs, errs
+
+
+@pytest.mark.parametrize("S", [2, 5, 6, 8, 9, 13, 16, 17, 24, 31, 32, 40, 48, 63, 64])
+def test_commit_joint_one_sort_path_and_its_bound(oracle, S):
+    """Joint waves take one sort with the half membership in the two low bits of the shifted key when every
+    member key of the wavefront is below 2^62 (kernels.h: regs_joint_packed, 17 slots and up), the two-sort or counting form
+    otherwise.  Both against the oracle: keys right up to the bound (2^62 - 1), ties, zeros, empty halves; then
+    the same planes with one key of 2^62 or more planted in some wavefronts only."""
+    rng = np.random.default_rng(900 + S)
+    G = 6000 if S > 32 else 20000
+    big = rng.integers(0, 1 << 62, size=(S, G), dtype=np.uint64)
+    small = rng.integers(0, 6, size=(S, G), dtype=np.uint64)
+    sel = rng.random((S, G))
+    match = np.where(sel < 0.5, big, small)
+    match = np.where(sel > 0.93, np.uint64((1 << 62) - 1), match)
+    match = np.ascontiguousarray(np.where((sel > 0.86) & (sel <= 0.93), np.uint64(0), match).astype(np.uint64))
+    m0, m1 = rand_masks(rng, S, G, joint_frac=0.8, empty_frac=0.05)
+    m0[::97] = 0  # empty incoming half next to a non-empty outgoing one
+    with raft_amd.Engine(G, S) as e:
+        e.upload_config(m0, m1)
+        e.upload_match(match)
+        e.commit()
+        assert np.array_equal(e.read_commit(), oracle.batch_committed(match, m0, m1))
+        # plant keys >= 2^62 in a few groups: their wavefronts leave the one-sort path, the others stay on it
+        planted = match.copy()
+        gs = rng.choice(G, size=max(1, G // 700), replace=False)
+        planted[rng.integers(0, S, size=len(gs)), gs] = rng.integers(1 << 62, 1 << 63, size=len(gs), dtype=np.uint64) * np.uint64(2) - np.uint64(1)
+        e.upload_match(planted)
+        e.commit()
+        assert np.array_equal(e.read_commit(), oracle.batch_committed(planted, m0, m1))

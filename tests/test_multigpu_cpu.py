@@ -112,3 +112,15 @@ def test_allgather_changed_gloo_world2():
         assert len(allp) == sum(ns.values())
         assert (np.diff(allp["group"].astype(np.int64)) > 0).all()  # global ids, sorted
         assert np.array_equal(allp["commit"], allp["group"] * 3 + rnd)
+
+
+def test_bench_refuses_a_rank_environment_that_disagrees_with_gpus():
+    """`bench.py --gpus N` under a WORLD_SIZE that is not N is an error (before anything touches a GPU), not a
+    silent single-rank run; without a rank environment and N > 1 it becomes the launcher instead."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and "WORLD_SIZE=3 but --gpus 2" in p.stderr and p.stdout == ""
