@@ -676,10 +676,13 @@ class Comm:
         return out, counts, total.value
 
 
-def batch_committed_index(match, in_mask, out_mask=None, device=0):
-    """quorum.BatchCommittedIndex: match u64 [S][G], slot masks [G] → u64 [G]."""
+def batch_committed_index(match, in_mask, out_mask=None, device=0, out=None):
+    """quorum.BatchCommittedIndex: match u64 [S][G], slot masks [G] → u64 [G] (`out`: a result array to reuse)."""
     S, G = match.shape
-    out = np.empty(G, dtype=np.uint64)
+    if out is None:
+        out = np.empty(G, dtype=np.uint64)
+    elif out.dtype != np.uint64 or out.shape != (G,) or not out.flags.c_contiguous:
+        raise ValueError("out must be a contiguous uint64 array of %d elements" % G)
     _check(load_library().rafthip_batch_committed_index(device, G, S, _ptr(match), _ptr(in_mask),
                                                         _ptr(out_mask), _ptr(out)))
     return out

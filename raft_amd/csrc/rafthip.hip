@@ -12,6 +12,8 @@
 
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
 #include <initializer_list>
 #include <mutex>
 #include <new>
@@ -2535,18 +2537,20 @@ int rafthip_commit_allgather_many(rafthip_comm** comms, int n, int advance, raft
 // refused):
 //   - a context (stream, events, page-locked staging slots) is taken from a process-wide pool and
 //     returned after the call: no engine, no device allocation, no page-locking per call;
-//   - the batch is cut into chunks; helper threads copy chunk k+1 of the caller's planes into a
-//     staging slot while the kernel of chunk k reads its slot over the link itself (zero-copy: the
-//     transfer and the quorum arithmetic are one pass) and writes its results into a page-locked
-//     result slot; the calling thread copies finished result slots to the caller's buffer.
+//   - the batch is cut into chunks; helper threads (kept with the context) copy the caller's planes
+//     chunk by chunk into staging slots; the calling thread launches a chunk's kernel as soon as the
+//     chunk is staged — the kernel reads its slot over the link itself (zero-copy: the transfer and
+//     the quorum arithmetic are one pass) and writes its results into a page-locked result slot; a
+//     third role, the retirer thread, copies finished result slots to the caller's buffer.  Up to
+//     eight chunks are in flight, so the link never waits for the host.
 // Device pointers take the resident path instead (an engine for the duration of the call).
 }  // extern "C"
 
 namespace {
 
-constexpr int kShotSlots = 4;
+constexpr int kShotSlots = 8;
 constexpr size_t kShotChunkBytes = 4u << 20;  // staged input bytes per chunk
-constexpr int kShotCopiers = 2;
+constexpr int kShotCopiers = 3;
 
 struct ShotCtx {
     int device = -1;
@@ -2560,7 +2564,54 @@ struct ShotCtx {
     size_t in_cap = 0, out_cap = 0;
     void* d_zero = nullptr;  // device zeros: the outgoing half of a non-joint call
     size_t zero_cap = 0;
+    // Staging helpers.  They live as long as the context (the pool keeps it until the process ends):
+    // starting and joining two threads costs more than staging a 2^16-group batch.
+    std::mutex mu;
+    std::condition_variable wake, idle;
+    std::vector<std::thread> helpers;
+    const std::function<void()>* job = nullptr;  // what the helpers run; valid while `running` > 0 or unclaimed
+    u64 generation = 0;
+    int unclaimed = 0, running = 0;
 };
+
+// Run `job` on `n` helper threads of the context (started on first use); shot_helpers_wait returns when all
+// of them have left it.
+int shot_helpers_start(ShotCtx* c, int n, const std::function<void()>* job) {
+    std::unique_lock<std::mutex> lock(c->mu);
+    while ((int)c->helpers.size() < n) {
+        try {
+            c->helpers.emplace_back([c] {
+                u64 seen = 0;
+                std::unique_lock<std::mutex> l(c->mu);
+                for (;;) {
+                    c->wake.wait(l, [&] { return c->generation != seen && c->unclaimed > 0; });
+                    seen = c->generation;
+                    --c->unclaimed;
+                    const std::function<void()>* j = c->job;
+                    l.unlock();
+                    (*j)();
+                    l.lock();
+                    if (--c->running == 0) c->idle.notify_all();
+                }
+            });
+            c->helpers.back().detach();  // parked on the condition variable for the life of the process
+        } catch (...) {
+            return fail(RAFTHIP_ENOMEM, "cannot start a staging thread");
+        }
+    }
+    c->job = job;
+    ++c->generation;
+    c->unclaimed = c->running = n;
+    lock.unlock();
+    c->wake.notify_all();
+    return RAFTHIP_OK;
+}
+
+void shot_helpers_wait(ShotCtx* c) {
+    std::unique_lock<std::mutex> lock(c->mu);
+    c->idle.wait(lock, [&] { return c->running == 0; });
+    c->job = nullptr;
+}
 
 std::mutex g_shot_mu;
 std::vector<ShotCtx*> g_shot_pool;
@@ -2686,14 +2737,23 @@ int shot_run(int device, u64 G, u32 S, size_t cell, size_t res, const void* plan
         shot_return(c);
         return rc;
     }
-    // Staging: chunk k goes to slot k % kShotSlots once chunk k - kShotSlots has been retired.  The
-    // calling thread stages chunk 0 itself (the helpers are still starting); helper threads take the
-    // following chunks in order.
+    // Three roles.  The calling thread launches: chunk k's kernel goes out as soon as the chunk is
+    // staged, alternating between the two streams, so that several chunks are queued on the link at any
+    // time.  Copier threads stage: chunk k goes to slot k % kShotSlots once chunk k - kShotSlots has
+    // been retired.  One retirer thread waits for each chunk's event in order and copies its results to
+    // the caller's buffer.  A batch of a few chunks does all three in line on the calling thread.
     std::atomic<u64> staged[kShotSlots];  // chunks staged into this slot so far
+    std::atomic<u64> launched{0};         // chunks whose kernel and event are in their stream
     std::atomic<u64> retired{0};          // chunks whose results have left their slot
-    std::atomic<u64> next_chunk{1};
+    std::atomic<u64> next_chunk{0};
+    std::atomic<int> role{0};
     std::atomic<bool> abort{false};
+    std::atomic<int> retire_error{(int)hipSuccess};
     for (auto& r : staged) r.store(0);
+    const bool trace = getenv("RAFTHIP_SHOT_TRACE") != nullptr;
+    double t_ready = 0, t_launch = 0, t_event = 0, t_out = 0;  // t_event / t_out: written by the one thread that retires
+    auto tick = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_begin = tick();
     auto stage_chunk = [&](u64 k) {
         const int slot = (int)(k % kShotSlots);
         while (retired.load(std::memory_order_acquire) + kShotSlots <= k) {
@@ -2708,39 +2768,21 @@ int shot_run(int device, u64 G, u32 S, size_t cell, size_t res, const void* plan
         if (out_mask) stage_copy(dst + planes_b + mask_b, static_cast<const char*>(out_mask) + g0 * mb, cnt * mb);
         staged[slot].fetch_add(1, std::memory_order_release);
     };
-    const int ncopiers = nchunks >= 4 ? want_copiers : 0;  // a small batch is staged by the calling thread alone
-    std::vector<std::thread> copiers;
-    for (int t = 0; t < ncopiers; ++t)
-        copiers.emplace_back([&] {
-            for (;;) {
-                const u64 k = next_chunk.fetch_add(1);
-                if (k >= nchunks || abort.load()) return;
-                stage_chunk(k);
-            }
-        });
-    const bool trace = getenv("RAFTHIP_SHOT_TRACE") != nullptr;
-    double t_ready = 0, t_launch = 0, t_event = 0, t_out = 0;
-    auto tick = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    const double t_begin = tick();
-    auto retire = [&](u64 k) -> int {
+    auto retire = [&](u64 k) -> hipError_t {
         const int slot = (int)(k % kShotSlots);
         const double t0 = tick();
-        HIP_TRY(hipEventSynchronize(c->done[slot]));
+        const hipError_t err = hipEventSynchronize(c->done[slot]);
+        if (err != hipSuccess) return err;
         const double t1 = tick();
         const u64 g0 = start[k], cnt = start[k + 1] - g0;
         memcpy(static_cast<char*>(result) + g0 * res, c->out[slot], cnt * res);
         retired.store(k + 1, std::memory_order_release);
         t_event += t1 - t0;
         t_out += tick() - t1;
-        return RAFTHIP_OK;
+        return hipSuccess;
     };
-    for (u64 k = 0; k < nchunks && !rc; ++k) {
+    auto launch_chunk = [&](u64 k) -> int {
         const int slot = (int)(k % kShotSlots);
-        const double t0 = tick();
-        if (k == 0 || !ncopiers) stage_chunk(k);
-        while (staged[slot].load(std::memory_order_acquire) < k / kShotSlots + 1) std::this_thread::yield();
-        const double t1 = tick();
-        t_ready += t1 - t0;
         rafthip_engine view;  // a chunk-sized view over the staging slot: the kernels read it over the link
         view.device = device;
         view.G = start[k + 1] - start[k];
@@ -2751,20 +2793,76 @@ int shot_run(int device, u64 G, u32 S, size_t cell, size_t res, const void* plan
         view.uniform = false;
         view.in_mask = c->d_in[slot] + planes_b;
         view.out_mask = out_mask ? static_cast<void*>(c->d_in[slot] + planes_b + mask_b) : c->d_zero;
-        rc = launch(view, c->d_in[slot], c->d_out[slot]);
-        if (!rc) {
+        int r = launch(view, c->d_in[slot], c->d_out[slot]);
+        if (!r) {
             hipError_t err = hipEventRecord(c->done[slot], view.stream);
-            if (err != hipSuccess) rc = fail(RAFTHIP_EIO, "hipEventRecord: %s", hipGetErrorString(err));
+            if (err != hipSuccess) r = fail(RAFTHIP_EIO, "hipEventRecord: %s", hipGetErrorString(err));
         }
+        return r;
+    };
+    int nhelpers = nchunks >= 4 ? want_copiers + 1 : 0;
+    const std::function<void()> helper = [&] {
+        if (role.fetch_add(1) == 0) {  // the retirer
+            (void)hipSetDevice(device);
+            for (u64 k = 0; k < nchunks; ++k) {
+                while (launched.load(std::memory_order_acquire) <= k) {
+                    if (abort.load()) return;
+                    std::this_thread::yield();
+                }
+                const hipError_t err = retire(k);
+                if (err != hipSuccess) {
+                    retire_error.store((int)err);
+                    abort.store(true);
+                    return;
+                }
+            }
+            return;
+        }
+        for (;;) {  // a copier
+            const u64 k = next_chunk.fetch_add(1);
+            if (k >= nchunks || abort.load()) return;
+            stage_chunk(k);
+        }
+    };
+    next_chunk.store(1);  // the calling thread stages chunk 0 itself while the helpers wake up
+    if (nhelpers && shot_helpers_start(c, nhelpers, &helper)) nhelpers = 0;  // no helper threads: everything in line
+    for (u64 k = 0; k < nchunks && !rc; ++k) {
+        const int slot = (int)(k % kShotSlots);
+        const double t0 = tick();
+        if (!nhelpers) {
+            if (k >= (u64)kShotSlots) {
+                const hipError_t err = retire(k - kShotSlots);
+                if (err != hipSuccess) rc = fail(RAFTHIP_EIO, "hipEventSynchronize: %s", hipGetErrorString(err));
+            }
+            if (!rc) stage_chunk(k);
+        } else if (k == 0) {
+            stage_chunk(0);
+        }
+        while (!rc && staged[slot].load(std::memory_order_acquire) < k / kShotSlots + 1) {
+            if (abort.load()) break;
+            std::this_thread::yield();
+        }
+        if (rc || abort.load()) break;
+        const double t1 = tick();
+        t_ready += t1 - t0;
+        rc = launch_chunk(k);
+        if (!rc) launched.store(k + 1, std::memory_order_release);
         t_launch += tick() - t1;
-        if (!rc && k >= 1) rc = retire(k - 1);  // while chunk k runs
     }
-    if (!rc) rc = retire(nchunks - 1);
     if (rc) abort.store(true);
-    for (auto& t : copiers) t.join();
+    if (nhelpers) {
+        shot_helpers_wait(c);
+        if (!rc && retire_error.load() != (int)hipSuccess)
+            rc = fail(RAFTHIP_EIO, "hipEventSynchronize: %s", hipGetErrorString((hipError_t)retire_error.load()));
+    } else {
+        for (u64 k = nchunks > (u64)kShotSlots ? nchunks - kShotSlots : 0; k < nchunks && !rc; ++k) {
+            const hipError_t err = retire(k);
+            if (err != hipSuccess) rc = fail(RAFTHIP_EIO, "hipEventSynchronize: %s", hipGetErrorString(err));
+        }
+    }
     if (trace)
-        fprintf(stderr, "shot: G %llu chunks %llu total %.0f us: wait-staged %.0f launch %.0f wait-gpu %.0f copy-out %.0f\n", (u64)G,
-                (u64)nchunks, (tick() - t_begin) * 1e6, t_ready * 1e6, t_launch * 1e6, t_event * 1e6, t_out * 1e6);
+        fprintf(stderr, "shot: G %llu chunks %llu total %.0f us: wait-staged %.0f launch %.0f | retirer: wait-gpu %.0f copy-out %.0f\n",
+                (u64)G, (u64)nchunks, (tick() - t_begin) * 1e6, t_ready * 1e6, t_launch * 1e6, t_event * 1e6, t_out * 1e6);
     if (rc) {
         (void)hipStreamSynchronize(c->stream);
         (void)hipStreamSynchronize(c->stream2);

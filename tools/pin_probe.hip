@@ -20,6 +20,19 @@ __global__ void k_touch(const unsigned long long* in, unsigned long long* out, s
     out[i] = a;
 }
 
+// two groups per lane, 16-byte loads
+__global__ void k_touch2(const ulonglong2* in, ulonglong2* out, size_t n_in2, size_t n_out2) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_out2) return;
+    ulonglong2 a = {0, 0};
+    for (size_t s = 0; s < n_in2 / n_out2; ++s) {
+        const ulonglong2 v = in[s * n_out2 + i];
+        a.x ^= v.x;
+        a.y ^= v.y;
+    }
+    out[i] = a;
+}
+
 static void par_copy(char* dst, const char* src, size_t n, int threads) {
     std::vector<std::thread> th;
     const size_t per = (n / threads + 4095) & ~(size_t)4095;
@@ -114,5 +127,44 @@ int main() {
     for (int r = 0; r < R; ++r) { hipLaunchKernelGGL(k_touch, dim3(n_out / 256), dim3(256), 0, st, (unsigned long long*)pi, (unsigned long long*)po, n_in, n_out); CK(hipStreamSynchronize(st)); }
     a = (now() - t) / R;
     printf("zero-copy kernel over hipHostMalloc memory: %.3f ms (%.1f GB/s in+out)\n", a * 1e3, (bin + bout) / a / 1e9);
+    // (g) the same kernel reading host memory but writing device memory: the read side of the link alone
+    t = now();
+    for (int r = 0; r < R; ++r) { hipLaunchKernelGGL(k_touch, dim3(n_out / 256), dim3(256), 0, st, (unsigned long long*)pi, d_out, n_in, n_out); CK(hipStreamSynchronize(st)); }
+    a = (now() - t) / R;
+    printf("zero-copy reads, result to device memory:   %.3f ms (%.1f GB/s in)\n", a * 1e3, bin / a / 1e9);
+    t = now();
+    for (int r = 0; r < R; ++r) { hipLaunchKernelGGL(k_touch2, dim3(n_out / 512), dim3(256), 0, st, (const ulonglong2*)pi, (ulonglong2*)d_out, n_in / 2, n_out / 2); CK(hipStreamSynchronize(st)); }
+    a = (now() - t) / R;
+    printf("zero-copy reads with 16-byte loads:         %.3f ms (%.1f GB/s in)\n", a * 1e3, bin / a / 1e9);
+    t = now();
+    for (int r = 0; r < R; ++r) { hipLaunchKernelGGL(k_touch2, dim3(n_out / 512), dim3(256), 0, st, (const ulonglong2*)pi, (ulonglong2*)po, n_in / 2, n_out / 2); CK(hipStreamSynchronize(st)); }
+    a = (now() - t) / R;
+    printf("zero-copy 16-byte loads, result to host:    %.3f ms (%.1f GB/s in+out)\n", a * 1e3, (bin + bout) / a / 1e9);
+    // (h) chunked DMA pipeline: pinned -> device by the copy engine, kernel on device memory, result back by
+    // the copy engine on a second stream
+    hipStream_t st2;
+    CK(hipStreamCreate(&st2));
+    for (size_t chunk : {(size_t)32768, (size_t)65536, (size_t)131072, (size_t)262144, (size_t)1048576}) {
+        const size_t nchunks = n_out / chunk;
+        std::vector<hipEvent_t> ev(nchunks);
+        for (auto& e : ev) CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        double best = 1e9;
+        for (int r = 0; r < R; ++r) {
+            t = now();
+            for (size_t k = 0; k < nchunks; ++k) {
+                // pinned layout [chunk k][5][chunk]: one contiguous copy per chunk
+                CK(hipMemcpyAsync(d_in + k * 5 * chunk, p_in + k * 5 * chunk, 5 * chunk * 8, hipMemcpyHostToDevice, st));
+                hipLaunchKernelGGL(k_touch, dim3(chunk / 256), dim3(256), 0, st, d_in + k * 5 * chunk, d_out + k * chunk, 5 * chunk, chunk);
+                CK(hipEventRecord(ev[k], st));
+                CK(hipStreamWaitEvent(st2, ev[k], 0));
+                CK(hipMemcpyAsync(p_out + k * chunk, d_out + k * chunk, chunk * 8, hipMemcpyDeviceToHost, st2));
+            }
+            CK(hipStreamSynchronize(st));
+            CK(hipStreamSynchronize(st2));
+            const double d = now() - t;
+            if (d < best) best = d;
+        }
+        printf("DMA pipeline, chunks of %7zu groups (%5.1f MB in): %.3f ms (%.1f GB/s in+out)\n", chunk, 5 * chunk * 8 / 1e6, best * 1e3, (bin + bout) / best / 1e9);
+    }
     return 0;
 }
