@@ -738,7 +738,31 @@ __global__ __launch_bounds__(kBlock) void k_pack_changed(const u64* __restrict__
     __shared__ u32 s_cnt[kMaxSpans];
     const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr u32 W = PAIRED ? 2 : 1;
+    constexpr u32 NWV = kBlock / 64, kMine = kMaxSpans / NWV;  // spans per wave: wave w owns spans w, w + NWV, ...
     const u64* tb = bits + (u64)tile * spans * W;
+    // Everything that does not depend on the tile's offset is asked for first — the ballot words of this
+    // wave's spans and the new commit values of their changed groups — so that those loads are in flight
+    // while wave 0 adds up the counts before the tile.
+    u64 b0[kMine], b1[kMine];
+    Vec<u64, 2> val[kMine];
+#pragma unroll
+    for (u32 k = 0; k < kMine; ++k) {
+        const u32 s = wave + k * NWV;
+        b0[k] = b1[k] = 0;
+        if (s < spans) {
+            b0[k] = tb[s * W];
+            if (PAIRED) b1[k] = tb[s * W + 1];
+        }
+    }
+#pragma unroll
+    for (u32 k = 0; k < kMine; ++k) {
+        const u32 s = wave + k * NWV;
+        if (PAIRED) {
+            if (((b0[k] | b1[k]) >> lane) & 1ull) val[k] = load_vec<u64, 2>(commit + ((u64)tile * spans + s) * 128 + 2 * lane);
+        } else {
+            if ((b0[k] >> lane) & 1ull) val[k].v[0] = commit[((u64)tile * spans + s) * 64 + lane];
+        }
+    }
     if (wave == 0) {
         const u32 sb = tile / kSuperTiles;
         u64 sum = 0;
@@ -753,35 +777,32 @@ __global__ __launch_bounds__(kBlock) void k_pack_changed(const u64* __restrict__
             s_off = sum;
             if (last) *total = sum + n;
         }
-    } else if (wave == 1 && lane < spans) {
-        u32 c = __popcll(tb[lane * W]);
-        if (PAIRED) c += __popcll(tb[lane * W + 1]);
-        s_cnt[lane] = c;
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (u32 k = 0; k < kMine; ++k)
+            if (wave + k * NWV < spans) s_cnt[wave + k * NWV] = __popcll(b0[k]) + __popcll(b1[k]);
     }
     if (n == 0) return;
     __syncthreads();
     const u64 lt = (1ull << lane) - 1ull;
-    for (u32 s = wave; s < spans; s += kBlock / 64) {
-        u64 pos = s_off;
-        for (u32 k = 0; k < s; ++k) pos += s_cnt[k];
+#pragma unroll
+    for (u32 k = 0; k < kMine; ++k) {
+        const u32 s = wave + k * NWV;
+        if (s >= spans) break;
+        u64 pos = s_off + __popcll(b0[k] & lt) + __popcll(b1[k] & lt);
+        for (u32 j = 0; j < s; ++j) pos += s_cnt[j];
         if (PAIRED) {
-            const u64 b0 = tb[2 * s], b1 = tb[2 * s + 1];
             const u64 g = ((u64)tile * spans + s) * 128 + 2 * lane;
-            pos += __popcll(b0 & lt) + __popcll(b1 & lt);
-            const bool c0 = (b0 >> lane) & 1ull, c1 = (b1 >> lane) & 1ull;
-            if (c0 | c1) {
-                const Vec<u64, 2> v = load_vec<u64, 2>(commit + g);
-                if (c0) {
-                    if (pos < max_pairs) out[pos] = Pair{group_base + g, v.v[0]};
-                    ++pos;
-                }
-                if (c1 && pos < max_pairs) out[pos] = Pair{group_base + g + 1, v.v[1]};
+            const bool c0 = (b0[k] >> lane) & 1ull, c1 = (b1[k] >> lane) & 1ull;
+            if (c0) {
+                if (pos < max_pairs) out[pos] = Pair{group_base + g, val[k].v[0]};
+                ++pos;
             }
+            if (c1 && pos < max_pairs) out[pos] = Pair{group_base + g + 1, val[k].v[1]};
         } else {
-            const u64 b = tb[s];
             const u64 g = ((u64)tile * spans + s) * 64 + lane;
-            pos += __popcll(b & lt);
-            if (((b >> lane) & 1ull) && pos < max_pairs) out[pos] = Pair{group_base + g, commit[g]};
+            if (((b0[k] >> lane) & 1ull) && pos < max_pairs) out[pos] = Pair{group_base + g, val[k].v[0]};
         }
     }
 }
