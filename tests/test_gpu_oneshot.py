@@ -44,6 +44,23 @@ def test_batch_vote_result_host_planes(S, G):
     assert np.array_equal(got, oracle.batch_tally_votes(votes, in_mask, np.zeros_like(in_mask))[0])
 
 
+def test_batch_committed_index_into_a_result_buffer_the_caller_keeps():
+    """A tick loop reuses its result slice: the same array filled by call after call, at sizes that take the
+    pipelined path (helper threads kept between calls) and the in-line one."""
+    rng = np.random.default_rng(77)
+    for G in (300_000, 300_000, 5_000, 300_000):
+        match = rng.integers(0, 1 << 62, size=(5, G), dtype=np.uint64)
+        in_mask, out_mask = _masks(rng, 5, G)
+        out = np.full(G, 0xDEAD, dtype=np.uint64)
+        got = raft_amd.batch_committed_index(match, in_mask, out_mask, out=out)
+        assert got is out
+        assert np.array_equal(out, oracle.batch_committed(match, in_mask, out_mask))
+    with pytest.raises(ValueError):
+        raft_amd.batch_committed_index(match, in_mask, out_mask, out=np.zeros(G, dtype=np.uint32))
+    with pytest.raises(ValueError):
+        raft_amd.batch_committed_index(match, in_mask, out_mask, out=np.zeros(G + 1, dtype=np.uint64))
+
+
 def test_batch_calls_from_several_threads_and_shrinking_sizes():
     """Each call takes a staging context from the pool; calls of different shapes follow one another
     (a smaller call finds a larger call's stale slots) and overlap across threads."""
