@@ -212,7 +212,17 @@ struct Report {
     u64* __restrict__ bits;    // ballot words: paired tiles 2 per span of 128 groups, lane tiles 1 per span of 64
     u32* __restrict__ counts;  // [tiles] changed groups per tile
     u32* __restrict__ super;   // [ceil(tiles / kSuperTiles)] sums of counts; zero before the pass
+    // The engine keeps two `super` arrays and alternates: a pass adds into one and, on the side, zeroes the
+    // other for its successor, which saves the memset launch in front of every pass.  NULL: the caller zeroes.
+    u32* __restrict__ super_next;
+    u32 super_words;
 };
+
+// Workgroup 0 zeroes the other `super` array (no pass is reading it: passes of one engine are stream-ordered).
+__device__ __forceinline__ void zero_next_super(const Report& rep) {
+    if (blockIdx.x == 0 && rep.super_next)
+        for (u32 i = threadIdx.x; i < rep.super_words; i += blockDim.x) rep.super_next[i] = 0;
+}
 
 // Lane-pair tiles (K1/K2): in chunk c lane t of wave w owns groups span*128 + 2t, +1
 // with span = c*NW + w; word 2*span holds the ballot of the even groups, 2*span+1
@@ -222,6 +232,7 @@ __device__ __forceinline__ void emit_changed(const bool (&ch)[CH][2], Report rep
     constexpr int NW = BLOCK / 64;
     __shared__ u32 wave_tot[NW];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    zero_next_super(rep);
     u32 tot = 0;
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
@@ -450,6 +461,7 @@ __device__ __forceinline__ void finish_lane(u64 res, u64 g, u64 G, u64* __restri
             commit[g] = res;
         }
         const u64 b = __ballot(chg);
+        zero_next_super(rep);
         if (lane == 0) {
             rep.bits[(u64)blockIdx.x * (kBlock / 64) + wave] = b;  // one span of 64 groups per wave
             wave_tot[wave] = __popcll(b);

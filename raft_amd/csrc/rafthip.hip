@@ -157,7 +157,8 @@ struct rafthip_engine {
     // changed-pair reporting (kernels.h: Report, k_pack_changed)
     u64* rep_bits = nullptr;    // ballot words, one bit per group of [0, stride)
     u32* rep_counts = nullptr;  // [stride / kBlock] per-tile counts (sized for the smallest tile)
-    u32* rep_super = nullptr;   // [ceil(tiles / kSuperTiles)] + the total as the u64 behind them
+    u32* rep_super = nullptr;   // two arrays of [ceil(tiles / kSuperTiles)] (used in turn) + the total as the u64 behind them
+    int rep_flip = 0;           // which of the two the next reporting pass adds into
     Pair* packed = nullptr;     // landing buffer when the caller's dst is pageable host memory
 
     // scatter
@@ -165,6 +166,7 @@ struct rafthip_engine {
     u64 ack_cap = 0;
     u64* d_rejected = nullptr;  // [0] acks without Progress, [1] msgs without Progress, [2] msgs of other types
     u64* h_scalar = nullptr;    // pinned, 4 x u64
+    u64* d_scalar = nullptr;    // the same words as kernels address them (a total stored there needs no copy back)
 
     // wire ingest
     u64* wire_hdr = nullptr;       // [G][H] per group: r.Term, pending ReadIndex ctx, its length, raft id per slot (wire.h)
@@ -247,7 +249,7 @@ bool small_commit_path(const rafthip_engine* e) {
 bool mid_commit_path(const rafthip_engine* e) { return !small_commit_path(e) && e->S <= 16 && !e->wide_bitonic; }
 
 template <int MODE>
-int launch_commit(rafthip_engine* e, u32* block_groups, Report rep = Report{nullptr, nullptr, nullptr},
+int launch_commit(rafthip_engine* e, u32* block_groups, Report rep = Report{nullptr, nullptr, nullptr, nullptr, 0},
                   u32 tiles_cap = 0) {
     constexpr bool CHANGED = MODE != kStore;  // needs the report buffers
     const u64 G = e->G;
@@ -363,7 +365,8 @@ int launch_commit(rafthip_engine* e, u32* block_groups, Report rep = Report{null
 struct ReportBufs {
     u64* bits;
     u32* counts;
-    u32* super;  // followed by the u64 total
+    u32* super;       // zero when the pass starts
+    u32* super_next;  // zeroed by the pass for its successor; NULL: `super` is zeroed by a memset in front of the pass
     u64* total;
     u32 tiles_cap;
 };
@@ -371,6 +374,8 @@ struct ReportBufs {
 u32 super_words(u32 tiles) { return (tiles + kSuperTiles - 1) / kSuperTiles; }
 // bytes of `super` + total for a plane of `stride` groups (smallest tile = kBlock), total 8-byte aligned
 size_t super_bytes(u64 stride) { return round_up((size_t)super_words((u32)(stride / kBlock)) * sizeof(u32), 8) + 8; }
+// the engine's own block: two such arrays and the total
+size_t super_pair_bytes(u64 stride) { return 2 * (super_bytes(stride) - 8) + 8; }
 
 int ensure_report_buffers(rafthip_engine* e, ReportBufs* rb) {
     // Sized for either tiling (a conf change may move an engine between them):
@@ -379,11 +384,14 @@ int ensure_report_buffers(rafthip_engine* e, ReportBufs* rb) {
     int rc;
     if ((rc = ensure(e, e->rep_bits, (size_t)e->stride / 8, false))) return rc;
     if ((rc = ensure(e, e->rep_counts, (size_t)tiles * sizeof(u32), false))) return rc;
-    if ((rc = ensure(e, e->rep_super, super_bytes(e->stride), false))) return rc;
+    if ((rc = ensure(e, e->rep_super, super_pair_bytes(e->stride), true))) return rc;  // both arrays start at zero
+    const size_t one = super_bytes(e->stride) - 8;
+    char* base = reinterpret_cast<char*>(e->rep_super);
     rb->bits = e->rep_bits;
     rb->counts = e->rep_counts;
-    rb->super = e->rep_super;
-    rb->total = reinterpret_cast<u64*>(reinterpret_cast<char*>(e->rep_super) + super_bytes(e->stride) - 8);
+    rb->super = reinterpret_cast<u32*>(base + (e->rep_flip ? one : 0));
+    rb->super_next = reinterpret_cast<u32*>(base + (e->rep_flip ? 0 : one));
+    rb->total = reinterpret_cast<u64*>(base + 2 * one);
     rb->tiles_cap = tiles;
     return RAFTHIP_OK;
 }
@@ -393,21 +401,28 @@ int ensure_report_buffers(rafthip_engine* e, ReportBufs* rb) {
 // changed / advanced groups to d_out (device-addressable, room for max_pairs) with
 // group ids rebased by group_base, leave the total in *rb.total.  Allocates nothing.
 template <int MODE>
-int report_pass(rafthip_engine* e, const ReportBufs& rb, u64 group_base, Pair* d_out, u64 max_pairs) {
+int report_pass(rafthip_engine* e, const ReportBufs& rb, u64 group_base, Pair* d_out, u64 max_pairs, u64* total_dst = nullptr) {
     static_assert(MODE != kStore, "a reporting mode");
-    HIP_TRY(hipMemsetAsync(rb.super, 0, (size_t)super_words(rb.tiles_cap) * sizeof(u32), e->stream));
+    u64* const total = total_dst ? total_dst : rb.total;  // e->d_scalar + k: the host reads it after its wait, no copy
+    if (!rb.super_next) HIP_TRY(hipMemsetAsync(rb.super, 0, (size_t)super_words(rb.tiles_cap) * sizeof(u32), e->stream));
     u32 bg = 0;
-    int rc = launch_commit<MODE>(e, &bg, Report{rb.bits, rb.counts, rb.super}, rb.tiles_cap);
-    if (rc) return rc;
+    int rc = launch_commit<MODE>(e, &bg, Report{rb.bits, rb.counts, rb.super, rb.super_next, super_words(rb.tiles_cap)}, rb.tiles_cap);
+    if (rc) {
+        // nothing was launched, or something was and may have added into `super`: either way the next pass
+        // must not trust the array this one was given
+        if (rb.super_next) (void)hipMemsetAsync(rb.super, 0, (size_t)super_words(rb.tiles_cap) * sizeof(u32), e->stream);
+        return rc;
+    }
+    if (rb.super_next) e->rep_flip ^= 1;  // the array this pass zeroed is the next one's
     const u32 tiles = (u32)((e->G + bg - 1) / bg);
     const bool paired = bg != (u32)kBlock;  // K1 / K2 tiles; the one-group-per-lane kernels use kBlock
     const u32 spans = paired ? bg / 128 : bg / 64;
     if (paired) {
         hipLaunchKernelGGL(k_pack_changed<true>, dim3(tiles), dim3(kBlock), 0, e->stream, rb.bits, rb.counts, rb.super,
-                           tiles, spans, e->commit, group_base, d_out, max_pairs, rb.total);
+                           tiles, spans, e->commit, group_base, d_out, max_pairs, total);
     } else {
         hipLaunchKernelGGL(k_pack_changed<false>, dim3(tiles), dim3(kBlock), 0, e->stream, rb.bits, rb.counts, rb.super,
-                           tiles, spans, e->commit, group_base, d_out, max_pairs, rb.total);
+                           tiles, spans, e->commit, group_base, d_out, max_pairs, total);
     }
     HIP_TRY(hipGetLastError());
     return RAFTHIP_OK;
@@ -581,8 +596,7 @@ static int commit_report(rafthip_engine* e, rafthip_commit_pair* dst, uint64_t m
         d_out = e->packed;
         cap = max_pairs < e->G ? max_pairs : e->G;
     }
-    if ((rc = report_pass<MODE>(e, rb, 0, d_out, cap))) return rc;
-    HIP_TRY(hipMemcpyAsync(e->h_scalar + 1, rb.total, sizeof(u64), hipMemcpyDeviceToHost, e->stream));
+    if ((rc = report_pass<MODE>(e, rb, 0, d_out, cap, e->d_scalar + 1))) return rc;  // the total lands in h_scalar[1]
     HIP_TRY(hipStreamSynchronize(e->stream));
     const u64 total = e->h_scalar[1];
     *n_out = total;
@@ -724,6 +738,7 @@ int rafthip_create(const rafthip_config* cfg, rafthip_engine** out) {
         if ((rc = ensure(e, e->commit, (size_t)e->stride * sizeof(u64)))) break;
         if ((rc = ensure(e, e->d_rejected, 4 * sizeof(u64)))) break;
         hipError_t err = hipHostMalloc(reinterpret_cast<void**>(&e->h_scalar), 4 * sizeof(u64), hipHostMallocDefault);
+        if (err == hipSuccess) err = hipHostGetDevicePointer(reinterpret_cast<void**>(&e->d_scalar), e->h_scalar, 0);
         if (err != hipSuccess) {
             rc = fail(RAFTHIP_ENOMEM, "hipHostMalloc: %s", hipGetErrorString(err));
             break;
@@ -1873,10 +1888,10 @@ int rafthip_commit_changed_static(rafthip_engine* e, rafthip_commit_pair* dst, u
     rb.bits = reinterpret_cast<u64*>(p);
     rb.counts = reinterpret_cast<u32*>(p + kStaticBitsBytes);
     rb.super = reinterpret_cast<u32*>(p + kStaticBitsBytes + kStaticCountsBytes);
+    rb.super_next = nullptr;  // the array is shared by every engine on this GPU: zeroed in front of each pass
     rb.total = reinterpret_cast<u64*>(p + kStaticBitsBytes + kStaticCountsBytes + kStaticSuperBytes - 8);
     rb.tiles_cap = (u32)(e->stride / kBlock);
-    if ((rc = report_pass<kChanged>(e, rb, 0, d_out, max_pairs))) return rc;
-    HIP_TRY(hipMemcpyAsync(e->h_scalar + 1, rb.total, sizeof(u64), hipMemcpyDeviceToHost, e->stream));
+    if ((rc = report_pass<kChanged>(e, rb, 0, d_out, max_pairs, e->d_scalar + 1))) return rc;  // the total lands in h_scalar[1]
     HIP_TRY(hipStreamSynchronize(e->stream));
     *n_changed = e->h_scalar[1];
     e->stats.changed_reported += *n_changed;

@@ -360,6 +360,37 @@ def test_commit_changed_pairs(oracle, S, uniform, flags):
         assert np.array_equal(e.read_commit(), want1)
 
 
+def test_commit_changed_pass_after_pass_across_tilings(oracle):
+    """The engine alternates between two arrays of per-64-tile sums, each reporting pass zeroing the other one for
+    its successor (no memset in front of a pass).  Passes in a row, with the engine moving between the 256-group
+    tiles of the wide kernel and the 2048-group tiles of K1 (different numbers of sums in use), must each report
+    exactly the groups that changed."""
+    rng = np.random.default_rng(4242)
+    S, G = 20, 600_001
+    match = rng.integers(1, 1 << 40, size=(S, G), dtype=np.uint64)
+    m0, m1 = rand_masks(rng, S, G, empty_frac=0)
+    with raft_amd.Engine(G, S) as e:
+        e.upload_match(match)
+        have = np.zeros(G, dtype=np.uint64)
+        for step, wide in enumerate([True, True, False, True, False, False, True]):
+            if wide:
+                e.upload_config(m0, m1)
+                kw = dict(in_mask=m0, out_mask=m1)
+            else:
+                e.set_uniform_config(5)
+                kw = dict(uniform_voters=5)
+            bump = rng.random((S, G)) < (0.2 if step % 2 else 0.002)
+            match[bump] += np.uint64(1 << 20)
+            e.upload_match(match)
+            want = oracle.batch_committed(match, **kw)
+            pairs, n = e.commit_changed()
+            ch = np.flatnonzero(want != have)
+            assert n == len(ch), step
+            assert np.array_equal(pairs["group"], ch.astype(np.uint64)), step
+            assert np.array_equal(pairs["commit"], want[ch]), step
+            have = want
+
+
 def test_partial_uploads_and_ranges(oracle):
     rng = np.random.default_rng(9)
     S, G = 5, 10000
