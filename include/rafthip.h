@@ -656,7 +656,13 @@ int rafthip_plane(rafthip_engine *e, int which, void **ptr, uint64_t *stride);
  * G groups, JointConfig{in,out}.CommittedIndex(l) (quorum/joint.go:49-56) with
  * l.AckedIndex(slot) = (match[slot][g], true); pass 0 for a voter the indexer
  * does not know (quorum/majority.go:149-161 leaves it 0).  Mask width as
- * rafthip_mask_bytes for S; out_mask may be NULL (non-joint). */
+ * rafthip_mask_bytes for S; out_mask may be NULL (non-joint).
+ * Host pointers: the planes are staged chunk by chunk through page-locked buffers
+ * that the library keeps between calls (with three staging threads and one result
+ * thread, parked while idle), the kernels read them over the link, the results are
+ * copied to `out`; nothing is allocated per call after the first of a size, and
+ * calls from several threads run side by side.  Returns when `out` is complete.
+ * Device pointers: evaluated in place through an engine that lives for the call. */
 int rafthip_batch_committed_index(int device, uint64_t num_groups, uint32_t num_slots,
                                   const uint64_t *match, const void *in_mask,
                                   const void *out_mask, uint64_t *out);
