@@ -126,7 +126,8 @@ __global__ __launch_bounds__(512) void k_apply(u64* __restrict__ match, u64 stri
 }
 
 int main(int argc, char** argv) {
-    const u64 N = 1ull << 24, G = 1ull << 22;
+    // usage: scatter_bin [slices [log2 acks [log2 groups]]]   (defaults: 512 slices, 2^24 acks over 2^22 groups)
+    const u64 N = 1ull << (argc > 2 ? atoi(argv[2]) : 24), G = 1ull << (argc > 3 ? atoi(argv[3]) : 22);
     const u32 ntiles = (u32)(G / T);
     const u32 nwg = argc > 1 ? (u32)atoi(argv[1]) : 512;  // slices
     const u64 slice = (N + nwg - 1) / nwg;
@@ -156,6 +157,8 @@ int main(int argc, char** argv) {
     CK(hipMemset(m_a, 0, (size_t)S * G * 8));
     CK(hipMemset(m_b, 0, (size_t)S * G * 8));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_apply), hipFuncAttributeMaxDynamicSharedMemorySize, S * T * 8));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_count), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(ntiles * 4)));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bin), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(ntiles * 4)));
     hipStream_t st;
     CK(hipStreamCreate(&st));
     hipEvent_t ev[6];
@@ -189,7 +192,7 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(a.data(), m_a, a.size() * 8, hipMemcpyDeviceToHost));
     CK(hipMemcpy(b.data(), m_b, b.size() * 8, hipMemcpyDeviceToHost));
     const bool same = memcmp(a.data(), b.data(), a.size() * 8) == 0;
-    printf("2^24 random acks, 2^22 groups x 9 slots, tiles of %u groups, %u slices\n", T, nwg);
+    printf("%llu random acks, %llu groups x 9 slots, tiles of %u groups, %u slices\n", N, G, T, nwg);
     printf("atomic  k_scatter_acks form              %8.1f us\n", t[0]);
     printf("binned  count %.1f + scan %.1f + bin %.1f + apply %.1f = %8.1f us\n", t[1], t[2], t[3], t[4], t[1] + t[2] + t[3] + t[4]);
     printf("planes %s\n", same ? "identical" : "DIFFER");
