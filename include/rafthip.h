@@ -641,6 +641,21 @@ int rafthip_commit_allgather(rafthip_comm *c, int advance, rafthip_commit_pair *
 int rafthip_commit_allgather_many(rafthip_comm **comms, int n, int advance, rafthip_commit_pair **dst,
                                   const uint64_t *max_pairs, uint64_t **counts, uint64_t *n_total);
 
+/* The dense form of the same exchange, for ticks in which most groups move (a pair
+ * is 16 bytes, a plane entry 8): rafthip_commit (advance == 0) or the term-guarded
+ * pass of rafthip_commit_advance (advance != 0) on this rank's engine, then ONE
+ * all-gather of the commit planes: dst[r * width + g] = the commit index (advance:
+ * raftLog.committed) of rank r's group g.  *width (may be NULL) = the largest plane
+ * stride of any rank, the same on every rank — rafthip_plane(e, RAFTHIP_PLANE_COMMIT)
+ * reports a rank's own; entries at g >= a rank's group count carry no meaning.  dst
+ * (host or device memory) holds dst_elems >= nranks * width elements; with dst NULL
+ * the call only reports *width (local, no collective).  Waits for the GPU.  Consumer: raft.maybeCommit, raft.go:755-758, diffing against the commit
+ * indexes it already holds; SURVEY.md 8(e) "dense fallback". */
+int rafthip_commit_allgather_dense(rafthip_comm *c, int advance, uint64_t *dst, uint64_t dst_elems, uint64_t *width);
+/* ... and for all n ranks that one thread drives (dst[i], dst_elems[i], width[i] belong to comms[i]). */
+int rafthip_commit_allgather_dense_many(rafthip_comm **comms, int n, int advance, uint64_t **dst,
+                                        const uint64_t *dst_elems, uint64_t *width);
+
 /* ---- zero-copy access for hosts that fill planes on the GPU themselves --- */
 
 #define RAFTHIP_PLANE_MATCH 0  /* uint64 [S][stride] */

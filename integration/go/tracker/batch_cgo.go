@@ -247,3 +247,23 @@ func (x *Exchange) Gather(advance bool, pairs []CommitPair, counts []uint64) (in
 	})
 	return int(total), err
 }
+
+// DenseWidth is the number of plane entries every rank contributes to GatherDense.
+func (x *Exchange) DenseWidth() (int, error) {
+	var w C.uint64_t
+	err := guarded(func() C.int { return C.rafthip_commit_allgather_dense(x.c, 0, nil, 0, &w) })
+	return int(w), err
+}
+
+// GatherDense is Gather for ticks in which most groups move: the commit pass, then
+// one all-gather of the commit planes.  planes holds nranks*DenseWidth() entries;
+// planes[r*width+g] is the commit index of rank r's group g.
+func (x *Exchange) GatherDense(advance bool, planes []uint64) error {
+	adv := C.int(0)
+	if advance {
+		adv = 1
+	}
+	return guarded(func() C.int {
+		return C.rafthip_commit_allgather_dense(x.c, adv, (*C.uint64_t)(unsafe.Pointer(&planes[0])), C.uint64_t(len(planes)), nil)
+	})
+}

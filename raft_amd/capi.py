@@ -47,6 +47,7 @@ SYMBOLS = [
     "rafthip_emit_heartbeats", "rafthip_plan_appends", "rafthip_commit_changed_static",
     "rafthip_comm_unique_id", "rafthip_comm_create", "rafthip_comm_create_all", "rafthip_comm_destroy",
     "rafthip_comm_info", "rafthip_commit_allgather", "rafthip_commit_allgather_many", "rafthip_commit_many",
+    "rafthip_commit_allgather_dense", "rafthip_commit_allgather_dense_many",
     "rafthip_init_progress_row",
 ]
 COMM_ID_BYTES = 128
@@ -191,6 +192,8 @@ def load_library():
         "rafthip_comm_destroy": (i32, [vp]),
         "rafthip_comm_info": (i32, [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(u64)]),
         "rafthip_commit_allgather": (i32, [vp, i32, vp, u64, vp, C.POINTER(u64)]),
+        "rafthip_commit_allgather_dense": (i32, [vp, i32, vp, u64, C.POINTER(u64)]),
+        "rafthip_commit_allgather_dense_many": (i32, [C.POINTER(vp), i32, i32, C.POINTER(vp), C.POINTER(u64), C.POINTER(u64)]),
         "rafthip_commit_allgather_many": (i32, [C.POINTER(vp), i32, i32, C.POINTER(vp), C.POINTER(u64),
                                                 C.POINTER(vp), C.POINTER(u64)]),
         "rafthip_host_alloc": (i32, [C.POINTER(vp), u64]),
@@ -674,6 +677,27 @@ class Comm:
             got = int(np.minimum(counts, self.max_pairs_per_rank).sum())
             out = out[:min(got, max_pairs)]
         return out, counts, total.value
+
+
+    def dense_width(self):
+        """Elements per rank in the dense exchange: the largest commit-plane stride of any rank."""
+        width = C.c_uint64()
+        _check(self._L.rafthip_commit_allgather_dense(self._h, 0, None, 0, C.byref(width)))
+        return width.value
+
+    def commit_allgather_dense(self, advance=False, dst=None, dst_elems=None):
+        """Commit pass + all-gather of the commit planes.  Returns (planes as a numpy uint64 [nranks][width] array —
+        or None when `dst`, a device / host address with room for dst_elems elements, was given —, width)."""
+        width = C.c_uint64()
+        out = None
+        if dst is None:
+            dst_elems = self.nranks * self.dense_width()
+            out = np.empty(dst_elems, dtype=np.uint64)
+            dst = out
+        _check(self._L.rafthip_commit_allgather_dense(self._h, int(bool(advance)), _ptr(dst), int(dst_elems), C.byref(width)))
+        if out is not None:
+            out = out.reshape(self.nranks, width.value)
+        return out, width.value
 
 
 def batch_committed_index(match, in_mask, out_mask=None, device=0, out=None):

@@ -2217,6 +2217,9 @@ struct rafthip_comm {
     u64* h_counts = nullptr; // pinned [nranks]
     u64 last_max = 0;        // largest per-rank count of the previous exchange
     bool have_history = false;
+    u64 width = 0;           // dense form: elements per rank = the largest plane stride of any rank
+    u64* d_plane_send = nullptr;  // [width] only when this rank's own plane is shorter than width
+    u64* d_plane_recv = nullptr;  // [nranks * width] landing buffer of the dense form for a pageable dst (first use)
 };
 
 namespace {
@@ -2235,7 +2238,8 @@ void comm_free(rafthip_comm* c) {
         DeviceGuard guard(c->e->device);
         if (c->e->stream) (void)hipStreamSynchronize(c->e->stream);
         if (c->nccl) (void)ncclCommDestroy(c->nccl);
-        for (void* b : {(void*)c->d_send, (void*)c->d_counts, (void*)c->d_recv, (void*)c->d_out})
+        for (void* b : {(void*)c->d_send, (void*)c->d_counts, (void*)c->d_recv, (void*)c->d_out, (void*)c->d_plane_send,
+                        (void*)c->d_plane_recv})
             if (b) (void)hipFree(b);
         if (c->h_counts) (void)hipHostFree(c->h_counts);
     }
@@ -2247,8 +2251,8 @@ void comm_free(rafthip_comm* c) {
 int comm_finish_create(rafthip_comm* c) {
     rafthip_engine* e = c->e;
     int rc;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_counts), (size_t)c->nranks * sizeof(u64)));
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_counts), (size_t)c->nranks * sizeof(u64), hipHostMallocDefault));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_counts), (size_t)c->nranks * 2 * sizeof(u64)));  // 2 words per rank at create
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_counts), (size_t)c->nranks * 2 * sizeof(u64), hipHostMallocDefault));
     ReportBufs rb;
     if ((rc = ensure_report_buffers(e, &rb))) return rc;  // so that the exchange itself allocates nothing
     if ((rc = ensure(e, e->term_first, (size_t)e->stride * sizeof(u64)))) return rc;
@@ -2380,6 +2384,74 @@ int exchange_many(rafthip_comm** comms, int n, rafthip_commit_pair** dst, const 
     return RAFTHIP_OK;
 }
 
+// The dense form: every engine's commit pass, then one all-gather of the commit planes — [rank][width]
+// — into dst[i] (device-addressable: straight into it; pageable: through a landing buffer).
+int exchange_dense(rafthip_comm** comms, int n, int advance, uint64_t** dst, const uint64_t* dst_elems, uint64_t* width_out) {
+    bool query = true;  // every dst NULL: report the width, do nothing else (a local call, no collective)
+    for (int i = 0; i < n; ++i) query = query && (!dst || !dst[i]);
+    if (query) {
+        if (!width_out) return fail(RAFTHIP_EINVAL, "dense exchange: dst and width are both NULL");
+        for (int i = 0; i < n; ++i) width_out[i] = comms[i]->width;
+        return RAFTHIP_OK;
+    }
+    for (int i = 0; i < n; ++i) {
+        rafthip_comm* c = comms[i];
+        const u64 need = (u64)c->nranks * c->width;
+        if (!dst || !dst[i] || !dst_elems || dst_elems[i] < need)
+            return fail(RAFTHIP_EINVAL, "dense exchange: dst[%d] needs room for %llu elements (nranks x width)", i, need);
+    }
+    u64* target[kMaxDevices];
+    for (int i = 0; i < n; ++i) {
+        rafthip_comm* c = comms[i];
+        rafthip_engine* e = c->e;
+        DeviceGuard guard(e->device);
+        int rc;
+        if (advance) {  // the term-guarded pass; its pair report goes nowhere
+            ReportBufs rb;
+            if ((rc = ensure_report_buffers(e, &rb))) return rc;
+            if ((rc = report_pass<kAdvance>(e, rb, 0, nullptr, 0))) return rc;
+        } else if ((rc = rafthip_commit(e))) {
+            return rc;
+        }
+        if (c->d_plane_send)  // this rank's plane is shorter than the width every rank sends
+            HIP_TRY(hipMemcpyAsync(c->d_plane_send, e->commit, (size_t)e->stride * sizeof(u64), hipMemcpyDeviceToDevice, e->stream));
+        u64* direct = nullptr;
+        {
+            hipPointerAttribute_t attr;
+            if (hipPointerGetAttributes(&attr, dst[i]) == hipSuccess) {
+                if (attr.type == hipMemoryTypeDevice) direct = reinterpret_cast<u64*>(dst[i]);
+                else if (attr.type == hipMemoryTypeHost && attr.devicePointer) direct = static_cast<u64*>(attr.devicePointer);
+            }
+            (void)hipGetLastError();
+        }
+        if (!direct) {
+            if ((rc = ensure(e, c->d_plane_recv, (size_t)c->nranks * c->width * sizeof(u64), false))) return rc;
+            direct = c->d_plane_recv;
+        }
+        target[i] = direct;
+    }
+    if (n > 1) NCCL_TRY(ncclGroupStart());
+    for (int i = 0; i < n; ++i) {
+        rafthip_comm* c = comms[i];
+        DeviceGuard guard(c->e->device);
+        const u64* send = c->d_plane_send ? c->d_plane_send : c->e->commit;
+        NCCL_TRY(ncclAllGather(send, target[i], (size_t)c->width, ncclUint64, c->nccl, c->e->stream));
+    }
+    if (n > 1) NCCL_TRY(ncclGroupEnd());
+    for (int i = 0; i < n; ++i) {
+        rafthip_comm* c = comms[i];
+        DeviceGuard guard(c->e->device);
+        const size_t bytes = (size_t)c->nranks * c->width * sizeof(u64);
+        if (target[i] == c->d_plane_recv) {
+            HIP_TRY(hipMemcpyAsync(dst[i], c->d_plane_recv, bytes, hipMemcpyDeviceToHost, c->e->stream));
+            c->e->stats.bytes_downloaded += bytes;
+        }
+        HIP_TRY(hipStreamSynchronize(c->e->stream));
+        if (width_out) width_out[i] = c->width;
+    }
+    return RAFTHIP_OK;
+}
+
 int check_comms(rafthip_comm** comms, int n) {
     if (!comms || n < 1 || n > kMaxDevices) return fail(RAFTHIP_EINVAL, "comms is NULL or n outside [1, %d]", kMaxDevices);
     for (int i = 0; i < n; ++i)
@@ -2407,8 +2479,9 @@ static int comm_agree_and_alloc(rafthip_comm* c, uint64_t max_pairs_per_rank) {
     rafthip_engine* e = c->e;
     int rc = comm_finish_create(c);
     if (rc) return rc;
-    c->h_counts[c->rank] = max_pairs_per_rank ? max_pairs_per_rank : e->G;  // pinned: safe source of an async copy
-    HIP_TRY(hipMemcpyAsync(c->d_counts + c->rank, c->h_counts + c->rank, sizeof(u64), hipMemcpyHostToDevice, e->stream));
+    c->h_counts[2 * c->rank] = max_pairs_per_rank ? max_pairs_per_rank : e->G;  // pinned: safe source of an async copy
+    c->h_counts[2 * c->rank + 1] = e->stride;
+    HIP_TRY(hipMemcpyAsync(c->d_counts + 2 * c->rank, c->h_counts + 2 * c->rank, 2 * sizeof(u64), hipMemcpyHostToDevice, e->stream));
     return RAFTHIP_OK;
 }
 
@@ -2435,20 +2508,25 @@ int rafthip_comm_create(rafthip_engine* e, const rafthip_comm_id* id, int rank, 
             break;
         }
         if ((rc = comm_agree_and_alloc(c, max_pairs_per_rank))) break;
-        // the capacity every rank uses = the largest one asked for: an in-place all-gather + max
-        r = ncclAllGather(c->d_counts + rank, c->d_counts, 1, ncclUint64, c->nccl, e->stream);
+        // the capacity every rank uses = the largest one asked for, the dense width = the largest plane
+        // stride: an in-place all-gather of both + max
+        r = ncclAllGather(c->d_counts + 2 * rank, c->d_counts, 2, ncclUint64, c->nccl, e->stream);
         if (r != ncclSuccess) {
             rc = fail(RAFTHIP_EIO, "ncclAllGather: %s", ncclGetErrorString(r));
             break;
         }
-        hipError_t err = hipMemcpyAsync(c->h_counts, c->d_counts, (size_t)nranks * sizeof(u64), hipMemcpyDeviceToHost, e->stream);
+        hipError_t err = hipMemcpyAsync(c->h_counts, c->d_counts, (size_t)nranks * 2 * sizeof(u64), hipMemcpyDeviceToHost, e->stream);
         if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
         if (err != hipSuccess) {
             rc = fail(RAFTHIP_EIO, "capacity exchange: %s", hipGetErrorString(err));
             break;
         }
-        for (int k = 0; k < nranks; ++k) c->cap = c->h_counts[k] > c->cap ? c->h_counts[k] : c->cap;
+        for (int k = 0; k < nranks; ++k) {
+            c->cap = c->h_counts[2 * k] > c->cap ? c->h_counts[2 * k] : c->cap;
+            c->width = c->h_counts[2 * k + 1] > c->width ? c->h_counts[2 * k + 1] : c->width;
+        }
         c->cap = round_up(c->cap, kGatherGranule);
+        if (c->width > e->stride && (rc = ensure(e, c->d_plane_send, (size_t)c->width * sizeof(u64)))) break;  // zeroed
         if ((rc = comm_alloc_payload(c))) break;
         if ((rc = ensure(e, c->d_out, (size_t)c->cap * nranks * sizeof(Pair), false))) break;
     } while (0);
@@ -2477,6 +2555,8 @@ int rafthip_comm_create_all(rafthip_engine** engines, int n, const uint64_t* gro
             if (devs[k] == devs[i]) return fail(RAFTHIP_EINVAL, "engines %d and %d share device %d: one rank per GPU", k, i, devs[i]);
         if (!max_pairs_per_rank && engines[i]->G > cap) cap = engines[i]->G;
     }
+    u64 width = 0;
+    for (int i = 0; i < n; ++i) width = engines[i]->stride > width ? engines[i]->stride : width;
     cap = round_up(cap, kGatherGranule);
     ncclComm_t handles[kMaxDevices];
     NCCL_TRY(ncclCommInitAll(handles, n, devs));
@@ -2495,11 +2575,13 @@ int rafthip_comm_create_all(rafthip_engine** engines, int n, const uint64_t* gro
         c->nranks = n;
         c->group_base = group_base[i];
         c->cap = cap;
+        c->width = width;
         if (rc) continue;
         DeviceGuard guard(c->e->device);
         if ((rc = comm_finish_create(c))) continue;
         if ((rc = comm_alloc_payload(c))) continue;
-        rc = ensure(c->e, c->d_out, (size_t)c->cap * n * sizeof(Pair), false);
+        if ((rc = ensure(c->e, c->d_out, (size_t)c->cap * n * sizeof(Pair), false))) continue;
+        if (width > c->e->stride) rc = ensure(c->e, c->d_plane_send, (size_t)width * sizeof(u64));
     }
     if (rc) {
         char keep[sizeof(g_err)];
@@ -2533,6 +2615,19 @@ int rafthip_commit_allgather(rafthip_comm* c, int advance, rafthip_commit_pair* 
     if (max_pairs > 0 && !dst) return fail(RAFTHIP_EINVAL, "dst is NULL with max_pairs > 0");
     return advance ? exchange_many<kAdvance>(&c, 1, &dst, &max_pairs, &counts, n_total)
                    : exchange_many<kChanged>(&c, 1, &dst, &max_pairs, &counts, n_total);
+}
+
+int rafthip_commit_allgather_dense(rafthip_comm* c, int advance, uint64_t* dst, uint64_t dst_elems, uint64_t* width) {
+    int rc = check_comms(&c, 1);
+    if (rc) return rc;
+    return exchange_dense(&c, 1, advance, &dst, &dst_elems, width);
+}
+
+int rafthip_commit_allgather_dense_many(rafthip_comm** comms, int n, int advance, uint64_t** dst, const uint64_t* dst_elems,
+                                        uint64_t* width) {
+    int rc = check_comms(comms, n);
+    if (rc) return rc;
+    return exchange_dense(comms, n, advance, dst, dst_elems, width);
 }
 
 int rafthip_commit_allgather_many(rafthip_comm** comms, int n, int advance, rafthip_commit_pair** dst,

@@ -119,3 +119,44 @@ def test_per_rank_cap_clips_payload_not_count():
         comm.close()
         a.close()
         b.close()
+
+
+@pytest.mark.parametrize("G,S,uniform", [(70_001, 5, 5), (9_000, 12, 0)])
+def test_one_rank_dense_allgather_is_the_commit_plane(G, S, uniform):
+    """The dense form of the exchange ("dense fallback"): commit pass + all-gather of the commit
+    planes, into a pageable buffer, a device buffer and a page-locked one; with the term guard too."""
+    import torch
+    a, b, rng = _engine_pair(G, S, 41 + S, uniform)
+    comm = Comm(a, comm_unique_id(), 0, 1, group_base=0)
+    try:
+        width = comm.dense_width()
+        assert width >= G and width % 4096 == 0
+        recs = _acks(rng, G, S, 3 * G, 1 << 41)
+        a.scatter_acks(recs)
+        b.scatter_acks(recs)
+        b.commit()
+        want = b.read_commit()
+        planes, w = comm.commit_allgather_dense()
+        assert w == width and planes.shape == (1, width)
+        assert np.array_equal(planes[0, :G], want)
+        buf = torch.zeros(width, dtype=torch.int64, device="cuda:0")
+        none, w = comm.commit_allgather_dense(dst=buf.data_ptr(), dst_elems=width)
+        assert none is None and np.array_equal(buf[:G].cpu().numpy().view(np.uint64), want)
+        pin = PinnedArray(width, np.uint64)
+        comm.commit_allgather_dense(dst=pin.array.ctypes.data, dst_elems=width)
+        assert np.array_equal(pin.array[:G], want)
+        with pytest.raises(raft_amd.RafthipError):
+            comm.commit_allgather_dense(dst=buf.data_ptr(), dst_elems=width - 1)
+        # the term-guarded pass: the plane is raftLog.committed afterwards
+        tf = np.full(G, 1 << 41, dtype=np.uint64)
+        tl = np.full(G, (1 << 41) + (1 << 19), dtype=np.uint64)
+        for e in (a, b):
+            e.upload_commit(np.zeros(G, dtype=np.uint64))
+            e.upload_term_range(tf, tl)
+        b.commit_advance()
+        planes, _ = comm.commit_allgather_dense(advance=True)
+        assert np.array_equal(planes[0, :G], b.read_commit())
+    finally:
+        comm.close()
+        a.close()
+        b.close()

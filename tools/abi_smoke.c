@@ -252,11 +252,30 @@ int main(void) {
         if (r != 0 || nr != 1 || cap < G) failures++;
         OK(rafthip_commit_allgather(c, 0, pairs, 100, cnt, &tot)); /* host dst, clipped to 100 pairs */
         OK(rafthip_commit_allgather(c, 1, NULL, 0, NULL, &tot));
+        {   /* the dense form: the width first (dst NULL), then a heap buffer sized to the element */
+            uint64_t width = 0, w2 = 0;
+            OK(rafthip_commit_allgather_dense(c, 0, NULL, 0, &width));
+            if (width < G) failures++;
+            uint64_t *plane = malloc(width * sizeof *plane);
+            OK(rafthip_commit_allgather_dense(c, 0, plane, width, &w2));
+            if (w2 != width) failures++;
+            FAILS(rafthip_commit_allgather_dense(c, 0, plane, width - 1, NULL)); /* too small */
+            OK(rafthip_commit_allgather_dense(c, 1, plane, width, NULL));
+            free(plane);
+        }
         OK(rafthip_comm_destroy(c));
         OK(rafthip_comm_create_all(&e, 1, base, 0, all));
         rafthip_commit_pair *dsts[1] = {pairs};
         uint64_t *cnts[1] = {cnt};
         OK(rafthip_commit_allgather_many(all, 1, 0, dsts, mp, cnts, &tot));
+        {
+            uint64_t width = 0;
+            OK(rafthip_commit_allgather_dense_many(all, 1, 0, NULL, NULL, &width));
+            uint64_t *plane = malloc(width * sizeof *plane), *planes[1];
+            planes[0] = plane;
+            OK(rafthip_commit_allgather_dense_many(all, 1, 0, planes, &width, NULL));
+            free(plane);
+        }
         OK(rafthip_comm_destroy(all[0]));
         FAILS(rafthip_comm_create(e, &id, 1, 1, 0, 0, &c)); /* rank outside [0, nranks) */
     }
