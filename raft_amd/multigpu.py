@@ -125,3 +125,32 @@ def commit_changed_allgather(engine, group_base=0, device=None, group=None, max_
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return buf[: 2 * n].cpu().numpy().view(PAIR_DTYPE), n_total
     return _allgather_pairs(buf, n, dist.get_world_size(group), group), n_total
+
+
+def allgather_commit_planes(plane, width, group=None):
+    """The dense form of the exchange restated on torch.distributed (CPU tests over gloo; the product
+    path is rafthip_commit_allgather_dense): every rank contributes its commit plane padded to `width`
+    entries — the largest plane stride of any rank, agreed beforehand — and receives [world][width]."""
+    import torch
+    import torch.distributed as dist
+
+    mine = np.zeros(width, dtype=np.uint64)
+    mine[: len(plane)] = plane
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return mine.reshape(1, width)
+    world = dist.get_world_size(group)
+    outs = [torch.empty(width, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(outs, torch.from_numpy(mine.view(np.int64)), group=group)
+    return np.stack([o.numpy().view(np.uint64) for o in outs])
+
+
+def agree_width(stride, group=None):
+    """The dense width: the largest plane stride over the ranks (what rafthip_comm_create agrees on)."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return int(stride)
+    t = torch.tensor([int(stride)], dtype=torch.int64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return int(t.item())

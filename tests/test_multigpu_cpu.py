@@ -114,6 +114,47 @@ def test_allgather_changed_gloo_world2():
         assert np.array_equal(allp["commit"], allp["group"] * 3 + rnd)
 
 
+def _dense_worker(rank, world, port, total, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    first, count = multigpu.shard_range(total, rank, world)
+    stride = (count + 4095) // 4096 * 4096 + (4096 if rank == 1 else 0)  # ranks with different plane strides
+    width = multigpu.agree_width(stride)
+    plane = (np.arange(count, dtype=np.uint64) + np.uint64(first)) * np.uint64(7)  # a function of the GLOBAL id
+    planes = multigpu.allgather_commit_planes(plane, width)
+    q.put((rank, width, planes.tobytes()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_dense_plane_allgather_gloo_world2():
+    """The dense form of the exchange at world size 2: the agreed width is the larger stride, every rank receives
+    [world][width], and rank r's first `count_r` entries are its groups' commit indexes."""
+    world, total = 2, 9001
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dense_worker, args=(r, world, port, total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=100) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    widths = {w for _, w, _ in got}
+    assert len(widths) == 1
+    width = widths.pop()
+    views = [np.frombuffer(b, dtype=np.uint64).reshape(world, width) for _, _, b in got]
+    assert np.array_equal(views[0], views[1])
+    for r in range(world):
+        first, count = multigpu.shard_range(total, r, world)
+        assert width >= count
+        assert np.array_equal(views[0][r, :count], (np.arange(count, dtype=np.uint64) + np.uint64(first)) * np.uint64(7))
+
+
 def test_bench_refuses_a_rank_environment_that_disagrees_with_gpus():
     """`bench.py --gpus N` under a WORLD_SIZE that is not N is an error (before anything touches a GPU), not a
     silent single-rank run; without a rank environment and N > 1 it becomes the launcher instead."""
