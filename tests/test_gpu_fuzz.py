@@ -2,6 +2,8 @@
 shadow of every plane: after each compute call the engine's outputs must equal
 the oracle evaluated on the shadow.  Catches offset / stride / partial-range
 mistakes that whole-plane tests cannot."""
+import os
+
 import numpy as np
 import pytest
 
@@ -18,7 +20,7 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("S,G,seed", [(1, 1, 0), (3, 5000, 1), (5, 4097, 2), (8, 12289, 3), (9, 3000, 4), (16, 2500, 5),
                                       (17, 2049, 6), (40, 1500, 7), (64, 700, 8)])
 def test_random_call_sequences(oracle, S, G, seed):
-    rng = np.random.default_rng(9000 + seed)
+    rng = np.random.default_rng(9000 + seed + 1000 * int(os.environ.get("RAFTHIP_FUZZ_ROUND", "0")))  # more rounds: set the variable
     mdt = gu.mask_dtype(S)
     full = mdt((1 << S) - 1 if S < 64 else gu.U64MAX)
     sh = dict(match=np.zeros((S, G), np.uint64), votes=np.zeros((S, G), np.uint8), commit=np.zeros(G, np.uint64),
@@ -276,7 +278,7 @@ def test_random_call_sequences(oracle, S, G, seed):
                     want = oracle.batch_check_quorum(sh["active"], S, sh["self"], **lrn_kw())
                 assert np.array_equal(e.read_quorum_active(a, n), want[a:a + n]), step
                 assert np.array_equal(e.read_active(), sh["active"]), step
-        assert checked[0] >= 25
+        assert checked[0] >= (25 if os.environ.get("RAFTHIP_FUZZ_ROUND", "0") == "0" else 10)  # the committed seeds check at least 25 calls each
         assert np.array_equal(e.read_match(), sh["match"])
         assert np.array_equal(e.read_acks(), sh["acks"])
         assert np.array_equal(e.read_term_range()[1], sh["tl"])
