@@ -642,6 +642,27 @@ def main():
         extra["own_stream_engines_GBs"] = round(2000 * G_BATCH * BYTES_PER_GROUP / dt / 1e9, 1)
         if not np.array_equal(own[0].read_commit()[idx], want):
             raise SystemExit("bench: own-stream result differs from the oracle")
+        # a multi-shard host's commit step with the changed pairs reported (here: nothing changes, the steady
+        # state between acks): shard by shard — a launch pair and a wait each — against rafthip_commit_report_many
+        try:
+            own_set = EngineSet(own)
+            for e in own:
+                e.commit_changed(max_pairs=0)
+            own_set.commit_report(max_pairs=0)
+            torch.cuda.synchronize()
+            a = time.perf_counter()
+            for _ in range(20):
+                for e in own:
+                    e.commit_changed(max_pairs=0)
+            t_each = (time.perf_counter() - a) / 20
+            a = time.perf_counter()
+            for _ in range(20):
+                own_set.commit_report(max_pairs=0)
+            t_many = (time.perf_counter() - a) / 20
+            extra["commit_changed_%d_shards_one_by_one_us" % nb] = round(1e6 * t_each, 1)
+            extra["commit_changed_%d_shards_report_many_us" % nb] = round(1e6 * t_many, 1)
+        except Exception as ex:
+            extra["commit_report_many_error"] = str(ex)[:200]
         for e in own:
             e.close()
     del mats

@@ -489,6 +489,18 @@ int rafthip_commit(rafthip_engine *e);
  * after.  Calls on any of the engines must not overlap this one. */
 int rafthip_commit_many(rafthip_engine *const *engines, uint32_t n);
 
+/* rafthip_commit_changed (advance == 0) or rafthip_commit_advance (advance != 0)
+ * for n engines at once: dst[i] / max_pairs[i] / n_out[i] are engine i's pair
+ * buffer (host or device memory; NULL with max_pairs 0 = count only), its room
+ * and its count, exactly as in the single-engine calls (consumer: raft.maybeCommit,
+ * raft.go:755-758 / raftLog.maybeCommit, log.go:447-456).  Up to 32 engines on one
+ * GPU with the same uniform config of 1..8 voters take one commit launch, one pack
+ * launch and one wait together; any other set is served engine by engine.  Runs on
+ * engines[0]'s stream (streams of the other engines that still hold work are joined
+ * to it first); waits for the GPU.  An engine may appear only once. */
+int rafthip_commit_report_many(rafthip_engine *const *engines, uint32_t n, int advance,
+                               rafthip_commit_pair *const *dst, const uint64_t *max_pairs, uint64_t *n_out);
+
 /* Same pass, but also reports the groups whose commit index differs from the
  * commit plane's previous content, sorted by group.  Waits for the GPU.
  * *n_changed = number of pairs; up to max_pairs of them are copied to dst

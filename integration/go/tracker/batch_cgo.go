@@ -198,6 +198,27 @@ func CommitMany(engines []*BatchEngine) error {
 	return guarded(func() C.int { return C.rafthip_commit_many(&hs[0], C.uint32_t(len(hs))) })
 }
 
+// MaybeCommitMany is MaybeCommit (advance) or the changed-pair report for several
+// shards of one GPU in one call.  pairs[i] must be memory from TickBuffer (C
+// memory: cgo forbids handing C an array of Go pointers), room[i] its capacity in
+// pairs; counts[i] receives shard i's pair count.
+func MaybeCommitMany(engines []*BatchEngine, advance bool, pairs []*CommitPair, room []uint64, counts []uint64) error {
+	hs := make([]*C.rafthip_engine, len(engines))
+	ds := make([]*C.rafthip_commit_pair, len(engines))
+	for i, b := range engines {
+		hs[i] = b.e
+		ds[i] = (*C.rafthip_commit_pair)(unsafe.Pointer(pairs[i]))
+	}
+	adv := C.int(0)
+	if advance {
+		adv = 1
+	}
+	return guarded(func() C.int {
+		return C.rafthip_commit_report_many(&hs[0], C.uint32_t(len(hs)), adv, &ds[0],
+			(*C.uint64_t)(unsafe.Pointer(&room[0])), (*C.uint64_t)(unsafe.Pointer(&counts[0])))
+	})
+}
+
 // Exchange is one rank of the path's only collective (rafthip_comm_*): after the commit pass the
 // changed (or advanced) pairs of every GPU of the node are all-gathered over RCCL, so that the host
 // loop that feeds raft.maybeCommit (raft.go:755-758) and Ready's HardState.Commit (rawnode.go:141-156)

@@ -47,7 +47,7 @@ SYMBOLS = [
     "rafthip_emit_heartbeats", "rafthip_plan_appends", "rafthip_commit_changed_static",
     "rafthip_comm_unique_id", "rafthip_comm_create", "rafthip_comm_create_all", "rafthip_comm_destroy",
     "rafthip_comm_info", "rafthip_commit_allgather", "rafthip_commit_allgather_many", "rafthip_commit_many",
-    "rafthip_commit_allgather_dense", "rafthip_commit_allgather_dense_many",
+    "rafthip_commit_allgather_dense", "rafthip_commit_allgather_dense_many", "rafthip_commit_report_many",
     "rafthip_init_progress_row",
 ]
 COMM_ID_BYTES = 128
@@ -193,6 +193,7 @@ def load_library():
         "rafthip_comm_info": (i32, [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(u64)]),
         "rafthip_commit_allgather": (i32, [vp, i32, vp, u64, vp, C.POINTER(u64)]),
         "rafthip_commit_allgather_dense": (i32, [vp, i32, vp, u64, C.POINTER(u64)]),
+        "rafthip_commit_report_many": (i32, [C.POINTER(vp), u32, i32, C.POINTER(vp), C.POINTER(u64), C.POINTER(u64)]),
         "rafthip_commit_allgather_dense_many": (i32, [C.POINTER(vp), i32, i32, C.POINTER(vp), C.POINTER(u64), C.POINTER(u64)]),
         "rafthip_commit_allgather_many": (i32, [C.POINTER(vp), i32, i32, C.POINTER(vp), C.POINTER(u64),
                                                 C.POINTER(vp), C.POINTER(u64)]),
@@ -621,6 +622,28 @@ class EngineSet:
     def commit(self, n=None):
         """One launch over the first n engines (default: all)."""
         _check(self._L.rafthip_commit_many(self._arr, len(self.engines) if n is None else n))
+
+    def commit_report(self, advance=False, max_pairs=None, dsts=None):
+        """rafthip_commit_report_many: commit_changed / commit_advance of every engine in one call.  Returns
+        (list of numpy PAIR_DTYPE arrays — or None when `dsts`, device / host addresses with room for max_pairs[i]
+        pairs each, were given —, counts)."""
+        n = len(self.engines)
+        if max_pairs is None:
+            max_pairs = [e.G for e in self.engines]
+        elif np.isscalar(max_pairs):
+            max_pairs = [int(max_pairs)] * n
+        outs = None
+        if dsts is None:
+            outs = [np.empty(m, dtype=PAIR_DTYPE) for m in max_pairs]
+            dsts = [o.ctypes.data if m else None for o, m in zip(outs, max_pairs)]
+        darr = (C.c_void_p * n)(*dsts)
+        marr = (C.c_uint64 * n)(*max_pairs)
+        counts = (C.c_uint64 * n)()
+        _check(self._L.rafthip_commit_report_many(self._arr, n, int(bool(advance)), darr, marr, counts))
+        counts = [int(c) for c in counts]
+        if outs is not None:
+            outs = [o[:min(c, m)] for o, c, m in zip(outs, counts, max_pairs)]
+        return outs, counts
 
 
 def comm_unique_id():

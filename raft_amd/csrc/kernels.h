@@ -219,8 +219,8 @@ struct Report {
 };
 
 // Workgroup 0 zeroes the other `super` array (no pass is reading it: passes of one engine are stream-ordered).
-__device__ __forceinline__ void zero_next_super(const Report& rep) {
-    if (blockIdx.x == 0 && rep.super_next)
+__device__ __forceinline__ void zero_next_super(const Report& rep, u32 tile) {
+    if (tile == 0 && rep.super_next)
         for (u32 i = threadIdx.x; i < rep.super_words; i += blockDim.x) rep.super_next[i] = 0;
 }
 
@@ -228,11 +228,11 @@ __device__ __forceinline__ void zero_next_super(const Report& rep) {
 // with span = c*NW + w; word 2*span holds the ballot of the even groups, 2*span+1
 // of the odd ones.
 template <int CH, int BLOCK>
-__device__ __forceinline__ void emit_changed(const bool (&ch)[CH][2], Report rep) {
+__device__ __forceinline__ void emit_changed(const bool (&ch)[CH][2], Report rep, u32 tile) {  // tile: index within the engine
     constexpr int NW = BLOCK / 64;
     __shared__ u32 wave_tot[NW];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    zero_next_super(rep);
+    zero_next_super(rep, tile);
     u32 tot = 0;
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
@@ -242,7 +242,7 @@ __device__ __forceinline__ void emit_changed(const bool (&ch)[CH][2], Report rep
             Vec<u64, 2> w;
             w.v[0] = b0;
             w.v[1] = b1;
-            store_vec<u64, 2>(rep.bits + ((u64)blockIdx.x * (CH * NW) + (u64)(c * NW + wave)) * 2, w);
+            store_vec<u64, 2>(rep.bits + ((u64)tile * (CH * NW) + (u64)(c * NW + wave)) * 2, w);
         }
     }
     if (lane == 0) wave_tot[wave] = tot;
@@ -251,8 +251,8 @@ __device__ __forceinline__ void emit_changed(const bool (&ch)[CH][2], Report rep
         u32 run = 0;
 #pragma unroll
         for (int w = 0; w < NW; ++w) run += wave_tot[w];
-        rep.counts[blockIdx.x] = run;
-        if (run) atomicAdd(rep.super + blockIdx.x / kSuperTiles, run);
+        rep.counts[tile] = run;
+        if (run) atomicAdd(rep.super + tile / kSuperTiles, run);
     }
 }
 
@@ -276,7 +276,7 @@ struct LogBounds {  // per-group planes used by kAdvance only
 // Store the tile's results; report changed / advanced pairs as MODE says.
 template <int CH, int BLOCK, int MODE>
 __device__ __forceinline__ void finish_tile(const Vec<u64, 2> (&res)[CH], u64 base, u64 G,
-                                            u64* __restrict__ commit, LogBounds lb, Report rep) {
+                                            u64* __restrict__ commit, LogBounds lb, Report rep, u32 tile) {
     if constexpr (MODE != kStore) {
         bool ch[CH][2];
         Vec<u64, 2> nxt[CH];
@@ -303,7 +303,7 @@ __device__ __forceinline__ void finish_tile(const Vec<u64, 2> (&res)[CH], u64 ba
         }
 #pragma unroll
         for (int c = 0; c < CH; ++c) store_stream<u64, 2>(commit + base + (u64)c * BLOCK * 2, nxt[c]);
-        emit_changed<CH, BLOCK>(ch, rep);
+        emit_changed<CH, BLOCK>(ch, rep, tile);
     } else {
 #pragma unroll
         for (int c = 0; c < CH; ++c) store_stream<u64, 2>(commit + base + (u64)c * BLOCK * 2, res[c]);
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(kCommitBlock) void k_commit_uniform(const u64* __re
             for (int s = 0; s < V; ++s) a[s] = in[c][s].v[j];
             res[c].v[j] = committed_fixed<V>(a);
         }
-    finish_tile<kCH, kCommitBlock, MODE>(res, base, G, commit, lb, rep);
+    finish_tile<kCH, kCommitBlock, MODE>(res, base, G, commit, lb, rep, blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------
@@ -382,6 +382,54 @@ __global__ __launch_bounds__(kCommitBlock) void k_commit_uniform_many(const Many
         }
         store_stream<u64, 2>(commit + base + (u64)c * kCommitBlock * 2, res);
     }
+}
+
+// K1m in a reporting mode (rafthip_commit_report_many): the shards' changed / advanced pairs are reported
+// per shard, exactly as the single-engine pass reports them — every shard has its own ballot words, counts
+// and sums, and the tile index that addresses them is the tile's index within its shard.
+struct ManyReport {
+    u32 n;
+    u32 first_tile[kManyMax + 1];
+    const u64* match[kManyMax];
+    u64* commit[kManyMax];
+    u64 stride[kManyMax];
+    u64 groups[kManyMax];
+    const u64* term_start[kManyMax];  // kAdvance only
+    const u64* last_index[kManyMax];
+    u64* bits[kManyMax];
+    u32* counts[kManyMax];
+    u32* super[kManyMax];
+    u32* super_next[kManyMax];
+    u32 super_words[kManyMax];
+};
+
+template <int V, int MODE>
+__global__ __launch_bounds__(kCommitBlock) void k_commit_uniform_many_report(const ManyReport sh) {
+    static_assert(MODE != kStore, "the plain pass is k_commit_uniform_many");
+    u32 k = 0;
+    for (u32 i = 1; i < sh.n; ++i) k = blockIdx.x >= sh.first_tile[i] ? i : k;
+    const u64* __restrict__ match = sh.match[k];
+    const u64 stride = sh.stride[k];
+    const u32 tile = blockIdx.x - sh.first_tile[k];
+    const u64 base = (u64)tile * kTileGroups + threadIdx.x * 2;
+    Vec<u64, 2> in[kCH][V];
+#pragma unroll
+    for (int c = 0; c < kCH; ++c)
+#pragma unroll
+        for (int s = 0; s < V; ++s)
+            in[c][s] = load_stream<u64, 2>(match + (u64)s * stride + base + (u64)c * kCommitBlock * 2);
+    Vec<u64, 2> res[kCH];
+#pragma unroll
+    for (int c = 0; c < kCH; ++c)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            u64 a[V];
+#pragma unroll
+            for (int s = 0; s < V; ++s) a[s] = in[c][s].v[j];
+            res[c].v[j] = committed_fixed<V>(a);
+        }
+    finish_tile<kCH, kCommitBlock, MODE>(res, base, sh.groups[k], sh.commit[k], LogBounds{sh.term_start[k], sh.last_index[k]},
+                                         Report{sh.bits[k], sh.counts[k], sh.super[k], sh.super_next[k], sh.super_words[k]}, tile);
 }
 
 // ---------------------------------------------------------------------------
@@ -438,7 +486,7 @@ __global__ __launch_bounds__(BLOCK) void k_commit_masked(const u64* __restrict__
             }
             res[c].v[j] = r;
         }
-    finish_tile<CH, BLOCK, MODE>(res, base, G, commit, lb, rep);
+    finish_tile<CH, BLOCK, MODE>(res, base, G, commit, lb, rep, blockIdx.x);
 }
 constexpr int kMidBlock = 256;                 // tile shape of K2 at 9..16 slots
 constexpr int kMidTileGroups = kMidBlock * 2;  // 512; divides kPlaneAlign
@@ -461,7 +509,7 @@ __device__ __forceinline__ void finish_lane(u64 res, u64 g, u64 G, u64* __restri
             commit[g] = res;
         }
         const u64 b = __ballot(chg);
-        zero_next_super(rep);
+        zero_next_super(rep, blockIdx.x);
         if (lane == 0) {
             rep.bits[(u64)blockIdx.x * (kBlock / 64) + wave] = b;  // one span of 64 groups per wave
             wave_tot[wave] = __popcll(b);
@@ -736,13 +784,10 @@ __global__ __launch_bounds__(kBlock) void k_commit_wide(const u64* __restrict__ 
 constexpr u32 kMaxSpans = 16;  // 2048-group tile of K1/K2
 
 template <bool PAIRED>
-__global__ __launch_bounds__(kBlock) void k_pack_changed(const u64* __restrict__ bits,
-                                                         const u32* __restrict__ counts,
-                                                         const u32* __restrict__ super, u32 ntiles,
-                                                         u32 spans, const u64* __restrict__ commit,
-                                                         u64 group_base, Pair* __restrict__ out,
-                                                         u64 max_pairs, u64* __restrict__ total) {
-    const u32 tile = blockIdx.x;
+__device__ __forceinline__ void pack_tile(u32 tile, const u64* __restrict__ bits, const u32* __restrict__ counts,
+                                          const u32* __restrict__ super, u32 ntiles, u32 spans,
+                                          const u64* __restrict__ commit, u64 group_base, Pair* __restrict__ out,
+                                          u64 max_pairs, u64* __restrict__ total) {
     const u32 n = counts[tile];
     const bool last = tile == ntiles - 1;
     if (n == 0 && !last) return;  // uniform over the workgroup
@@ -817,6 +862,36 @@ __global__ __launch_bounds__(kBlock) void k_pack_changed(const u64* __restrict__
             if (((b0[k] >> lane) & 1ull) && pos < max_pairs) out[pos] = Pair{group_base + g, val[k].v[0]};
         }
     }
+}
+
+template <bool PAIRED>
+__global__ __launch_bounds__(kBlock) void k_pack_changed(const u64* __restrict__ bits,
+                                                         const u32* __restrict__ counts,
+                                                         const u32* __restrict__ super, u32 ntiles,
+                                                         u32 spans, const u64* __restrict__ commit,
+                                                         u64 group_base, Pair* __restrict__ out,
+                                                         u64 max_pairs, u64* __restrict__ total) {
+    pack_tile<PAIRED>(blockIdx.x, bits, counts, super, ntiles, spans, commit, group_base, out, max_pairs, total);
+}
+
+// The same for the shards of rafthip_commit_report_many (K1 tiles): one launch, every shard packed into its own buffer.
+struct ManyPack {
+    u32 n;
+    u32 first_tile[kManyMax + 1];
+    const u64* bits[kManyMax];
+    const u32* counts[kManyMax];
+    const u32* super[kManyMax];
+    const u64* commit[kManyMax];
+    Pair* out[kManyMax];
+    u64 max_pairs[kManyMax];
+    u64* total[kManyMax];
+};
+
+__global__ __launch_bounds__(kBlock) void k_pack_changed_many(const ManyPack sh) {
+    u32 k = 0;
+    for (u32 i = 1; i < sh.n; ++i) k = blockIdx.x >= sh.first_tile[i] ? i : k;
+    pack_tile<true>(blockIdx.x - sh.first_tile[k], sh.bits[k], sh.counts[k], sh.super[k], sh.first_tile[k + 1] - sh.first_tile[k],
+                    kTileGroups / 128, sh.commit[k], 0, sh.out[k], sh.max_pairs[k], sh.total[k]);
 }
 
 // ---------------------------------------------------------------------------

@@ -1852,6 +1852,153 @@ int rafthip_commit_many(rafthip_engine* const* engines, uint32_t n) {
     return rc;
 }
 
+}  // extern "C"
+
+// rafthip_commit_changed / rafthip_commit_advance over several engines.  One GPU, the K1 shape and the same
+// voter count in every shard: one commit launch, one pack launch and one wait for all of them; otherwise engine by
+// engine — same results.
+template <int MODE>
+static int commit_report_many(rafthip_engine* const* engines, u32 n, rafthip_commit_pair* const* dst, const uint64_t* max_pairs,
+                              uint64_t* n_out) {
+    rafthip_engine* e0 = engines[0];
+    bool one_launch = n <= (u32)kManyMax;
+    for (u32 i = 0; i < n; ++i) {
+        const rafthip_engine* e = engines[i];
+        if (e->device != e0->device || !e->uniform || e->uniform_voters != e0->uniform_voters) one_launch = false;
+        for (u32 k = 0; k < i; ++k)
+            if (engines[k] == e) return fail(RAFTHIP_EINVAL, "engines[%u] and engines[%u] are the same engine", k, i);
+    }
+    if (e0->uniform_voters == 0 || e0->uniform_voters > 8) one_launch = false;
+    if (!one_launch) {
+        for (u32 i = 0; i < n; ++i) {
+            int rc = commit_report<MODE>(engines[i], dst ? dst[i] : nullptr, max_pairs ? max_pairs[i] : 0, &n_out[i]);
+            if (rc) return rc;
+        }
+        return RAFTHIP_OK;
+    }
+    DeviceGuard guard(e0->device);
+    hipStream_t st = e0->stream;
+    ManyReport sh{};
+    ManyPack pk{};
+    ReportBufs rb[kManyMax];
+    Pair* d_out[kManyMax];
+    bool landing[kManyMax];
+    u64 cap[kManyMax];
+    sh.n = pk.n = n;
+    u32 tiles = 0;
+    int rc;
+    for (u32 i = 0; i < n; ++i) {
+        rafthip_engine* e = engines[i];
+        const u64 mp = (dst && dst[i] && max_pairs) ? max_pairs[i] : 0;
+        if ((rc = ensure_report_buffers(e, &rb[i]))) return rc;
+        if (MODE == kAdvance) {
+            if ((rc = ensure(e, e->term_first, (size_t)e->stride * sizeof(u64)))) return rc;
+            if ((rc = ensure(e, e->term_last, (size_t)e->stride * sizeof(u64)))) return rc;
+        }
+        d_out[i] = mp ? device_addressable(dst[i]) : nullptr;
+        landing[i] = mp && !d_out[i];
+        cap[i] = mp;
+        if (landing[i]) {
+            if ((rc = ensure(e, e->packed, (size_t)e->stride * sizeof(Pair), false))) return rc;
+            d_out[i] = e->packed;
+            cap[i] = mp < e->G ? mp : e->G;
+        }
+    }
+    // Everything runs on engines[0]'s stream.  Another engine's stream is joined to it only if it still holds work
+    // (an upload's memset, a scatter): an idle stream costs one query.  No join afterwards: the call waits for the
+    // GPU before it returns, so nothing the caller issues later can overtake it.
+    hipEvent_t ev = nullptr;
+    for (u32 i = 1; i < n; ++i) {
+        if (engines[i]->stream == st) continue;
+        hipError_t err = hipStreamQuery(engines[i]->stream);
+        if (err == hipSuccess) continue;
+        if (err != hipErrorNotReady) return fail(RAFTHIP_EIO, "hipStreamQuery: %s", hipGetErrorString(err));
+        (void)hipGetLastError();
+        if (!ev) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        err = hipEventRecord(ev, engines[i]->stream);
+        if (err == hipSuccess) err = hipStreamWaitEvent(st, ev, 0);
+        if (err != hipSuccess) {
+            (void)hipEventDestroy(ev);
+            return fail(RAFTHIP_EIO, "stream join: %s", hipGetErrorString(err));
+        }
+    }
+    if (ev) (void)hipEventDestroy(ev);  // released once the recorded work is done
+    for (u32 i = 0; i < n; ++i) {
+        rafthip_engine* e = engines[i];
+        const u32 t = (u32)((e->G + kTileGroups - 1) / kTileGroups);
+        sh.first_tile[i] = pk.first_tile[i] = tiles;
+        tiles += t;
+        sh.match[i] = e->match;
+        sh.commit[i] = e->commit;
+        sh.stride[i] = e->stride;
+        sh.groups[i] = e->G;
+        sh.term_start[i] = e->term_first;
+        sh.last_index[i] = e->term_last;
+        sh.bits[i] = rb[i].bits;
+        sh.counts[i] = rb[i].counts;
+        sh.super[i] = rb[i].super;
+        sh.super_next[i] = rb[i].super_next;
+        sh.super_words[i] = super_words(rb[i].tiles_cap);
+        pk.bits[i] = rb[i].bits;
+        pk.counts[i] = rb[i].counts;
+        pk.super[i] = rb[i].super;
+        pk.commit[i] = e->commit;
+        pk.out[i] = d_out[i];
+        pk.max_pairs[i] = d_out[i] ? cap[i] : 0;
+        pk.total[i] = e->d_scalar + 1;  // lands in h_scalar[1]
+        e->stats.commit_launches++;
+        e->stats.groups_evaluated += e->G;
+    }
+    sh.first_tile[n] = pk.first_tile[n] = tiles;
+    switch (e0->uniform_voters) {
+#define RAFTHIP_CASE_MR(V)                                                                                     \
+    case V:                                                                                                   \
+        hipLaunchKernelGGL((k_commit_uniform_many_report<V, MODE>), dim3(tiles), dim3(kCommitBlock), 0, st, sh); \
+        break;
+        RAFTHIP_CASE_MR(1) RAFTHIP_CASE_MR(2) RAFTHIP_CASE_MR(3) RAFTHIP_CASE_MR(4)
+        RAFTHIP_CASE_MR(5) RAFTHIP_CASE_MR(6) RAFTHIP_CASE_MR(7) RAFTHIP_CASE_MR(8)
+#undef RAFTHIP_CASE_MR
+    }
+    hipLaunchKernelGGL(k_pack_changed_many, dim3(tiles), dim3(kBlock), 0, st, pk);
+    hipError_t err = hipGetLastError();
+    for (u32 i = 0; i < n; ++i) engines[i]->rep_flip ^= 1;  // the arrays this pass zeroed are the next one's
+    if (err == hipSuccess) err = hipStreamSynchronize(st);
+    if (err != hipSuccess) return fail(RAFTHIP_EIO, "commit_report_many: %s", hipGetErrorString(err));
+    bool copies = false;
+    for (u32 i = 0; i < n; ++i) {
+        rafthip_engine* e = engines[i];
+        const u64 total = e->h_scalar[1];
+        n_out[i] = total;
+        const u64 mp = (dst && dst[i] && max_pairs) ? max_pairs[i] : 0;
+        const u64 ncopy = total < mp ? total : mp;
+        if (landing[i] && ncopy) {
+            HIP_TRY(hipMemcpyAsync(dst[i], e->packed, ncopy * sizeof(Pair), hipMemcpyDeviceToHost, st));
+            copies = true;
+        }
+        e->stats.bytes_downloaded += ncopy * sizeof(Pair);
+        if (MODE == kAdvance) {
+            e->stats.advanced_reported += total;
+        } else {
+            e->stats.changed_reported += total;
+        }
+    }
+    if (copies) HIP_TRY(hipStreamSynchronize(st));
+    return RAFTHIP_OK;
+}
+
+extern "C" {
+
+int rafthip_commit_report_many(rafthip_engine* const* engines, uint32_t n, int advance, rafthip_commit_pair* const* dst,
+                               const uint64_t* max_pairs, uint64_t* n_out) {
+    if (!engines || n == 0 || !n_out) return fail(RAFTHIP_EINVAL, "engines/n_out is NULL or n is 0");
+    for (u32 i = 0; i < n; ++i) {
+        if (!engines[i]) return fail(RAFTHIP_EINVAL, "engines[%u] is NULL", i);
+        if (max_pairs && max_pairs[i] > 0 && (!dst || !dst[i])) return fail(RAFTHIP_EINVAL, "dst[%u] is NULL with max_pairs > 0", i);
+    }
+    return advance ? commit_report_many<kAdvance>(engines, n, dst, max_pairs, n_out)
+                   : commit_report_many<kChanged>(engines, n, dst, max_pairs, n_out);
+}
+
 int rafthip_commit_changed(rafthip_engine* e, rafthip_commit_pair* dst, uint64_t max_pairs,
                            uint64_t* n_changed) {
     return commit_report<kChanged>(e, dst, max_pairs, n_changed);

@@ -72,3 +72,94 @@ def test_commit_many_more_shards_than_one_launch_holds_and_mixed_configs():
     finally:
         for e in engines:
             e.close()
+
+
+@pytest.mark.parametrize("advance", [False, True])
+def test_commit_report_many_equals_the_single_engine_calls(advance):
+    """rafthip_commit_report_many (one commit launch + one pack launch + one wait for all shards) against
+    rafthip_commit_changed / rafthip_commit_advance on twin engines, pass after pass: ragged shards, pageable and
+    device destinations, clipped buffers, a pass in which nothing changes."""
+    import torch
+    rng = np.random.default_rng(77 + advance)
+    sizes = [1, 2047, 2049, 150_000, 4097, 70_000]
+    V, S = 5, 5
+    many, twins, mats = [], [], []
+    for G in sizes:
+        m = rng.integers(1, 1 << 30, size=(S, G), dtype=np.uint64)
+        pair = []
+        for _ in range(2):
+            e = raft_amd.Engine(G, S, device=0)
+            e.set_uniform_config(V)
+            e.upload_match(m)
+            if advance:
+                e.upload_commit(np.zeros(G, dtype=np.uint64))
+                e.upload_term_range(np.full(G, 1 << 29, dtype=np.uint64), np.full(G, 1 << 40, dtype=np.uint64))
+            pair.append(e)
+        many.append(pair[0])
+        twins.append(pair[1])
+        mats.append(m)
+    try:
+        es = EngineSet(many)
+        for step in range(4):
+            if step == 2:
+                pass  # nothing new: no pair anywhere
+            elif step:
+                for m, a, b in zip(mats, many, twins):
+                    bump = rng.random(m.shape) < 0.05
+                    m[bump] += np.uint64(1 << 29)
+                    a.upload_match(m)
+                    b.upload_match(m)
+            room = [max(1, G // 3) for G in sizes] if step == 3 else None  # clipped on the last pass
+            outs, counts = es.commit_report(advance=advance, max_pairs=room)
+            for i, (b, G) in enumerate(zip(twins, sizes)):
+                want, n = (b.commit_advance if advance else b.commit_changed)(max_pairs=room[i] if room else None)
+                assert counts[i] == n, (step, i)
+                assert np.array_equal(outs[i], want), (step, i)
+                assert np.array_equal(many[i].read_commit(), b.read_commit()), (step, i)
+            if step == 2:
+                assert counts == [0] * len(sizes)
+        # device destinations, count-only for one shard
+        for m, a, b in zip(mats, many, twins):
+            m += np.uint64(1 << 31)
+            a.upload_match(m)
+            b.upload_match(m)
+        bufs = [torch.zeros(2 * G, dtype=torch.int64, device="cuda:0") for G in sizes]
+        room = list(sizes)
+        room[1] = 0
+        dsts = [buf.data_ptr() if r else None for buf, r in zip(bufs, room)]
+        none, counts = es.commit_report(advance=advance, max_pairs=room, dsts=dsts)
+        assert none is None
+        for i, b in enumerate(twins):
+            want, n = (b.commit_advance if advance else b.commit_changed)()
+            assert counts[i] == n
+            if room[i]:
+                got = bufs[i][:2 * n].cpu().numpy().view(raft_amd.PAIR_DTYPE)
+                assert np.array_equal(got, want)
+    finally:
+        for e in many + twins:
+            e.close()
+
+
+def test_commit_report_many_mixed_configs_fall_back_and_duplicates_are_refused():
+    rng = np.random.default_rng(3)
+    G = 5000
+    m = rng.integers(1, 1 << 30, size=(6, G), dtype=np.uint64)
+    a = raft_amd.Engine(G, 6, device=0)
+    b = raft_amd.Engine(G, 6, device=0)
+    try:
+        a.set_uniform_config(5)
+        m0 = np.full(G, 0b111111, dtype=np.uint8)
+        m1 = np.where(rng.random(G) < 0.5, 0b000111, 0).astype(np.uint8)
+        b.upload_config(m0, m1)
+        a.upload_match(m)
+        b.upload_match(m)
+        outs, counts = EngineSet([a, b]).commit_report()
+        wa = oracle.batch_committed(m, uniform_voters=5)
+        wb = oracle.batch_committed(m, in_mask=m0, out_mask=m1)
+        assert counts == [int((wa != 0).sum()), int((wb != 0).sum())]
+        assert np.array_equal(outs[0]["commit"], wa[wa != 0]) and np.array_equal(outs[1]["commit"], wb[wb != 0])
+        with pytest.raises(raft_amd.RafthipError):
+            EngineSet([a, a]).commit_report()
+    finally:
+        a.close()
+        b.close()

@@ -201,6 +201,14 @@ int main(void) {
     OK(rafthip_upload_commit(e, FIRST, COUNT, tf));
     OK(rafthip_commit_advance(e, pairs, 100, &np));
     OK(rafthip_commit_advance(e, NULL, 0, &np));
+    {   /* the several-engines form, here with one engine (its config is per-group: served engine by engine) */
+        rafthip_commit_pair *dsts[1];
+        uint64_t mp[1] = {100}, cnt[1] = {0};
+        dsts[0] = pairs;
+        OK(rafthip_commit_report_many(&e, 1, 0, dsts, mp, cnt));
+        OK(rafthip_commit_report_many(&e, 1, 1, NULL, NULL, cnt));
+        FAILS(rafthip_commit_report_many(&e, 1, 0, NULL, mp, cnt)); /* room without a buffer */
+    }
     {   /* the allocation-free variant writes its pairs itself: page-locked landing buffer, sized to the byte */
         void *pin = NULL;
         OK(rafthip_host_alloc(&pin, 100 * sizeof *pairs));
