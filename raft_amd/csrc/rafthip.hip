@@ -1806,7 +1806,10 @@ int rafthip_commit_many(rafthip_engine* const* engines, uint32_t n) {
         HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         for (u32 i = 1; i < n; ++i) {
             if (engines[i]->stream == st) continue;
-            hipError_t err = hipEventRecord(ev, engines[i]->stream);
+            hipError_t err = hipStreamQuery(engines[i]->stream);  // an idle stream has nothing to wait for
+            if (err == hipSuccess) continue;
+            (void)hipGetLastError();
+            err = hipEventRecord(ev, engines[i]->stream);
             if (err == hipSuccess) err = hipStreamWaitEvent(st, ev, 0);
             if (err != hipSuccess) {
                 (void)hipEventDestroy(ev);
