@@ -6,6 +6,7 @@
  *
  *   cc -std=c11 -Iinclude tools/abi_smoke.c -Lraft_amd/lib -lrafthip -o abi_smoke
  */
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -43,6 +44,31 @@ static uint64_t rnd(void) { /* splitmix64 */
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
     return z ^ (z >> 31);
 }
+/* The stateless call at a size that takes its pipelined path (staging threads, result thread), from two threads at
+ * once, with heap buffers sized to the byte: match[s][g] = base + g + s, so 5 voters commit base + g + 2. */
+#define SHOT_G 300001u
+static void *shot_worker(void *arg) {
+    const uint64_t base = (uint64_t)(uintptr_t)arg;
+    uint64_t *m = malloc((size_t)5 * SHOT_G * 8), *res = malloc((size_t)SHOT_G * 8);
+    uint8_t *in = malloc(SHOT_G), *votes = malloc((size_t)5 * SHOT_G), *vr = malloc(SHOT_G);
+    for (uint32_t s = 0; s < 5; s++)
+        for (uint32_t g = 0; g < SHOT_G; g++) {
+            m[(size_t)s * SHOT_G + g] = base + g + s;
+            votes[(size_t)s * SHOT_G + g] = s < 3 ? 2 : 1; /* granted : rejected */
+        }
+    memset(in, 0x1F, SHOT_G);
+    long bad = 0;
+    for (int rep = 0; rep < 3; rep++) {
+        memset(res, 0, (size_t)SHOT_G * 8);
+        if (rafthip_batch_committed_index(0, SHOT_G, 5, m, in, NULL, res) != 0) bad++;
+        for (uint32_t g = 0; g < SHOT_G; g++) bad += res[g] != base + g + 2;
+        if (rafthip_batch_vote_result(0, SHOT_G, 5, votes, in, NULL, vr) != 0) bad++;
+        for (uint32_t g = 0; g < SHOT_G; g++) bad += vr[g] != RAFTHIP_VOTE_WON;
+    }
+    free(m), free(res), free(in), free(votes), free(vr);
+    return (void *)(intptr_t)bad;
+}
+
 static void *buf(size_t n) { /* exactly n bytes, filled with noise */
     unsigned char *p = malloc(n ? n : 1);
     for (size_t i = 0; i < n; i++) p[i] = (unsigned char)rnd();
@@ -242,6 +268,18 @@ int main(void) {
     uint64_t *one = buf(COUNT * 8);
     OK(rafthip_batch_committed_index(0, COUNT, S, match, in, out, one));
     OK(rafthip_batch_vote_result(0, COUNT, S, votes, in, out, r8));
+    {
+        pthread_t th[2];
+        void *bad = NULL;
+        for (int t = 0; t < 2; t++) pthread_create(&th[t], NULL, shot_worker, (void *)(uintptr_t)(1000u * (t + 1)));
+        for (int t = 0; t < 2; t++) {
+            pthread_join(th[t], &bad);
+            if (bad) {
+                fprintf(stderr, "stateless call from thread %d: %ld wrong results or errors\n", t, (long)(intptr_t)bad);
+                failures++;
+            }
+        }
+    }
     void *pin = NULL;
     OK(rafthip_host_alloc(&pin, n * sizeof *acks));
     if (pin) {
