@@ -215,6 +215,80 @@ def run_cfg3(raft_amd, torch, dev, local_rank, stream, rank, world, reps):
         raise
 
 
+def run_cfg2(raft_amd, torch, dev, local_rank, stream, reps):
+    """BASELINE configs[1]'s sibling / SURVEY.md §8(d) cfg2: 2^20 groups x 3 voters, non-joint, dist A; like the
+    headline it rotates over 12 resident shards in one rafthip_commit_many launch so that every pass reads HBM."""
+    import oracle
+    from raft_amd.capi import EngineSet
+    G, V, nb = 1 << 20, 3, 12
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(0x5EED0002)
+    engines = []
+    try:
+        for k in range(nb):
+            m = torch.randint(0, (1 << 63) - 1, (V, G), dtype=torch.int64, device=dev, generator=gen)
+            e = raft_amd.Engine(G, V, device=local_rank, stream=stream.cuda_stream)
+            e.set_uniform_config(V)
+            e.upload_match(m)
+            engines.append(e)
+            if k == 0:
+                first = m[:, :8192].cpu().numpy().astype(np.uint64)
+        es = EngineSet(engines)
+        with torch.cuda.stream(stream):
+            es.commit()
+        torch.cuda.synchronize()
+        if not np.array_equal(engines[0].read_commit(0, 8192), oracle.batch_committed(first, uniform_voters=V)):
+            raise SystemExit("bench cfg2: GPU result differs from the oracle")
+        sec = _timed(stream, es.commit, reps) / nb  # per 2^20-group pass
+        b = 8 * V + 8  # 32 B per group
+        return {"groups_per_pass": G, "voters": V, "shards_per_launch": nb, "us_per_pass": round(sec * 1e6, 3),
+                "groups_per_s": G / sec, "GBs": round(G * b / sec / 1e9, 1), "frac_of_hbm_peak": round(G * b / sec / 1e9 / HBM_PEAK_GBS, 4),
+                "kernel": "k_commit_uniform_many<3>", "bytes_per_group": b}
+    finally:
+        for e in engines:
+            e.close()
+
+
+def run_cfg4(raft_amd, torch, dev, local_rank, stream, reps):
+    """BASELINE configs[3] / SURVEY.md §8(d) cfg4: 2^26 groups x 5 voters, the three tallies: TallyVotes over
+    vote cells (40 % granted / 20 % rejected / 40 % missing), QuorumActive over RecentActive bits, the ReadIndex
+    ack quorum.  10 B per group for the three (5 + 1 vote bytes, 1 + 1, 1 + 1)."""
+    import oracle
+    G, V = 1 << 26, 5
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(0x5EED0004)
+    lut = torch.tensor([2, 2, 1, 0, 0], dtype=torch.uint8, device=dev)
+    votes = lut[torch.randint(0, 5, (V, G), device=dev, generator=gen)]
+    bits = torch.randint(0, 32, (G,), device=dev, generator=gen).to(torch.uint8)
+    e = raft_amd.Engine(G, V, device=local_rank, stream=stream.cuda_stream)
+    try:
+        e.set_uniform_config(V)
+        e.upload_votes(votes)
+        e.upload_active(bits)
+        e.upload_acks(bits)
+        with torch.cuda.stream(stream):
+            e.tally_votes()
+            e.quorum_active()
+            e.ack_quorum()
+        torch.cuda.synchronize()
+        n = 8192
+        res, _, _ = e.read_vote_result(0, n)
+        ores, _, _ = oracle.batch_tally_votes(votes[:, :n].cpu().numpy(), uniform_voters=V)
+        hb = bits[:n].cpu().numpy()
+        if not (np.array_equal(res, ores) and np.array_equal(e.read_quorum_active(0, n), oracle.batch_quorum_active(hb, V, uniform_voters=V))
+                and np.array_equal(e.read_ack_quorum(0, n), oracle.batch_ack_quorum(hb, V, uniform_voters=V))):
+            raise SystemExit("bench cfg4: GPU result differs from the oracle")
+        del votes, bits
+        t = [_timed(stream, f, reps) for f in (e.tally_votes, e.quorum_active, e.ack_quorum)]
+        sec = sum(t)
+        return {"groups": G, "voters": V, "tally_votes_ms": round(t[0] * 1e3, 4), "quorum_active_ms": round(t[1] * 1e3, 4),
+                "ack_quorum_ms": round(t[2] * 1e3, 4), "groups_per_s_three_tallies": G / sec,
+                "GBs": round(G * 10 / sec / 1e9, 1), "frac_of_hbm_peak": round(G * 10 / sec / 1e9 / HBM_PEAK_GBS, 4),
+                "bytes_per_group": 10}
+    finally:
+        e.close()
+
+
 def run_cfg5(raft_amd, torch, dev, local_rank, stream, rank, world, reps):
     """BASELINE configs[4] / SURVEY.md §8(d) cfg5: 2^24 groups over the ranks, 7 voters + 2 learners
     (S = 9 rows, quorum over 7); per pass 4 acks per group, uniformly random cell, index = the cell's
@@ -678,6 +752,13 @@ def main():
                 info, e, _ = runner(raft_amd, torch, dev, local_rank, stream, 0, 1, 3)
                 e.close()
                 extra[name] = info
+            except Exception as ex:
+                extra[name] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
+            torch.cuda.empty_cache()
+        # ... and the two single-GPU ones that are not the headline
+        for name, runner in (("cfg2_1M_x3", run_cfg2), ("cfg4_64M_tallies", run_cfg4)):
+            try:
+                extra[name] = runner(raft_amd, torch, dev, local_rank, stream, 5)
             except Exception as ex:
                 extra[name] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
             torch.cuda.empty_cache()
