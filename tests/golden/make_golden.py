@@ -15,7 +15,9 @@ Writes, into tests/golden/:
   figure7.json            the leader's side of testdata/probe_and_replicate.txt, line by line
   transcript_facts.json   what the interaction transcripts print (Progress strings, messages, vote and
                           quorum log lines) with line numbers: what the hand-reconstructed scenarios cite
-Nothing in these five files is typed by hand; tests/test_fixture_provenance.py regenerates them into a
+  confchange_shapes.json  every distinct tracker.Config printed by confchange/testdata/*.txt (shapes of joint
+                          configs with learners the reference reaches): inputs for differential tests
+Nothing in these six files is typed by hand; tests/test_fixture_provenance.py regenerates them into a
 scratch directory whenever /root/reference is present and requires byte identity.  Only inputs and
 expected outputs are kept: the expected value of a datadriven stanza is the LAST line of its output block
 (quorum/datadriven_test.go:213,222,234,242); `clean` records that the block holds no "<--" line, i.e. the
@@ -464,6 +466,32 @@ def transcript_facts(name):
     return {"progress": prog, "messages": msgs, "info": info}
 
 
+CONF_LINE = re.compile(r"^voters=\(([^)]*)\)(?:&&\(([^)]*)\))?(?:\s+learners=\(([^)]*)\))?(?:\s+learners_next=\(([^)]*)\))?"
+                       r"(\s+autoleave)?\s*$")
+
+
+def confchange_shapes():
+    """Every tracker.Config the conf-change transcripts print (confchange/testdata/*.txt: the `voters=(..)&&(..)
+    learners=(..) learners_next=(..)` line that follows each change, tracker/tracker.go:78-118 Config.String):
+    the shapes of incoming / outgoing / learner sets the reference itself reaches.  Distinct shapes, each with the
+    first place it is printed."""
+    seen = {}
+    d = os.path.join(REF, "confchange", "testdata")
+    for name in sorted(os.listdir(d)):
+        for ln, line in enumerate(open(os.path.join(d, name), encoding="utf-8").read().split("\n"), 1):
+            m = CONF_LINE.match(line)
+            if not m:
+                continue
+            ids = [[int(x) for x in (g or "").split()] for g in m.groups()[:4]]
+            key = json.dumps(ids)
+            if key not in seen:
+                seen[key] = {"incoming": ids[0], "outgoing": ids[1], "learners": ids[2], "learners_next": ids[3],
+                             "src": "confchange/testdata/%s:%d" % (name, ln)}
+    out = sorted(seen.values(), key=lambda c: c["src"])
+    assert len(out) >= 15 and any(c["outgoing"] for c in out) and any(c["learners_next"] for c in out), len(out)
+    return out
+
+
 def write_json(path, obj):
     with open(path, "w") as fh:
         json.dump(obj, fh, indent=1)
@@ -498,10 +526,16 @@ def generate(out_dir):
     kinds = [e["ev"] for e in fig7["events"]]
     assert kinds.count("recv") == 17 and kinds.count("commit") == 1 and len(fig7["votes"]) == 6, kinds
     write_json(os.path.join(out_dir, "figure7.json"), fig7)
+    write_json(os.path.join(out_dir, "confchange_shapes.json"),
+               {"_doc": "Every distinct tracker.Config the reference's conf-change transcripts print (incoming && outgoing "
+                        "voters, learners, learners_next), with the first line that prints it.  Shapes only: the transcripts "
+                        "hold no commit indexes, so these are inputs for the differential tests, not expected outputs.",
+                "configs": confchange_shapes()})
     return counts
 
 
-GENERATED = ["quorum_datadriven.json", "tables.json", "progress_tables.json", "transcript_facts.json", "figure7.json"]
+GENERATED = ["quorum_datadriven.json", "tables.json", "progress_tables.json", "transcript_facts.json", "figure7.json",
+             "confchange_shapes.json"]
 
 
 def main():
