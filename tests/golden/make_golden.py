@@ -8,8 +8,8 @@ Run in the build container (needs /root/reference, read as TEXT only):
 Writes, into tests/golden/:
   quorum_datadriven.json  the 127 datadriven cases of quorum/testdata/{majority_commit,joint_commit,
                           majority_vote,joint_vote}.txt
-  tables.json             the tables of TestCommit, TestLeaderAcknowledgeCommit, TestFindConflictByTerm and
-                          TestProgressUpdate, lifted from the Go table literals (golit.py)
+  tables.json             the tables of TestCommit, TestLeaderAcknowledgeCommit, TestFindConflictByTerm,
+                          TestLeaderAppResp and TestProgressUpdate, lifted from the Go table literals (golit.py)
   progress_tables.json    every table and imperative case of tracker/progress_test.go and
                           tracker/inflights_test.go, lifted the same way
   figure7.json            the leader's side of testdata/probe_and_replicate.txt, line by line
@@ -220,6 +220,22 @@ def make_tables():
         "src": _src("log_test.go", a, b),
         "rows": [{"from": r["ents"]["args"][0], "terms": r["ents"]["args"][1], "index": r["index"], "term": r["term"],
                   "want": r["want"]} for r in rows]}
+    # stepLeader's MsgAppResp branch end to end (raft.go:1333-1526): a 3-peer leader whose log holds the entries of
+    # `ents` plus the empty entry becomeLeader appends; peer 2 answers (index, reject, RejectHint = index); expected
+    # Progress[2].Match / Next afterwards, how many messages the leader sent, and their Index (prev) and Commit
+    body, a, b = golit.func_source(_go("raft_test.go"), "TestLeaderAppResp")
+    rows = golit.struct_table(body)
+    peers = re.search(r"withPeers\(([^)]*)\)", body)
+    frm = re.search(r"From:\s*(\d+),", body)
+    e0 = body.index("[]pb.Entry{", body.index("ents:"))
+    e1 = golit.match_brace(body, body.index("{", e0))
+    ents = golit.parse_expr(body[e0:e1 + 1])
+    assert ents[0] in ({}, []) and rows and peers and frm, (ents, peers, frm)  # ents[0] is MemoryStorage's dummy entry
+    out["TestLeaderAppResp"] = {
+        "src": _src("raft_test.go", a, b),
+        "peers": [int(x) for x in peers.group(1).split(",")], "from": int(frm.group(1)),
+        "log": [[e["Index"], e["Term"]] for e in ents[1:]],
+        "rows": [{k: (int(v) if not isinstance(v, bool) else v) for k, v in r.items()} for r in rows]}
     upd = progress_update_table()
     out["TestProgressUpdate"] = {"src": upd["src"], "prevM": upd["prev_match"], "prevN": upd["prev_next"], "rows": upd["rows"]}
     return out

@@ -51,8 +51,11 @@ class OracleDriver:
         else:
             m["type"], m["reject"] = po.EV_APP_RESP, reject
             if reject:
-                got = self.o.find_conflict_by_term(self.log.first, 0, self.log.terms, hint, log_term)
-                assert got == self.log.find_conflict_by_term(hint, log_term) and got[0] == resolved
+                if log_term > 0:  # raft.go:1362-1459: only then is the hint refined against the leader's log
+                    got = self.o.find_conflict_by_term(self.log.first, 0, self.log.terms, hint, log_term)
+                    assert got == self.log.find_conflict_by_term(hint, log_term) and got[0] == resolved
+                else:
+                    assert resolved == hint
                 aux = resolved
         act = self.py.step_progress(self.pl, self.cap, 0, self.active, self.acks, self.last, self.first, m,
                                     np.array([aux], dtype=np.uint64))

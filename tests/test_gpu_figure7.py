@@ -65,8 +65,12 @@ class EngineDriver:
         e.upload_inflights(pl["infl_meta"], pl["infl_bytes"], pl["ring_index"], pl["ring_bytes"])
         e.upload_active(active)
         e.upload_acks(acks)
-        # no entry of the new term yet: [last+1, last] is empty until the first append (RAFTHIP_MSG_APPENDED)
-        e.upload_term_range(np.full(G, last + 1, dtype=np.uint64), np.full(G, last, dtype=np.uint64))
+        # the entries that carry the leader's term: none yet in a real election — [last+1, last] is empty until the
+        # first append (RAFTHIP_MSG_APPENDED) — but a test may hand the leader a log that already holds some
+        # (raft_test.go:2617-2625 TestLeaderAppResp)
+        tf, tl = self.log.term_range(term)
+        assert tl == last
+        e.upload_term_range(np.full(G, tf, dtype=np.uint64), np.full(G, tl, dtype=np.uint64))
         e.upload_first_index(np.full(G, first, dtype=np.uint64))
         e.upload_commit(np.full(G, committed, dtype=np.uint64))
         e.upload_ids(self.ids)

@@ -1,0 +1,19 @@
+"""raft_test.go:2591-2657 TestLeaderAppResp on the engine through the C ABI: the response arrives as serialized
+bytes (rafthip_step_wire), the commit pass is rafthip_commit_advance, the sends follow rafthip_plan_appends and
+come back as SENT_APP records; several copies of the group with the voters in different slot orders must agree."""
+import pytest
+
+import leader_app_resp_util as lar
+import raft_amd
+from test_gpu_figure7 import EngineDriver
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("G", [1, 301])
+def test_leader_app_resp_table_on_the_engine(G):
+    t = lar.load()
+    fx = lar.fixture_for_driver(t)
+    for row in t["rows"]:
+        with raft_amd.Engine(G, len(fx["voters"])) as e:
+            lar.replay_row(t, row, EngineDriver(e, fx, G, 256))
