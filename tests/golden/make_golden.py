@@ -9,7 +9,7 @@ Writes, into tests/golden/:
   quorum_datadriven.json  the 127 datadriven cases of quorum/testdata/{majority_commit,joint_commit,
                           majority_vote,joint_vote}.txt
   tables.json             the tables of TestCommit, TestLeaderAcknowledgeCommit, TestFindConflictByTerm,
-                          TestLeaderAppResp and TestProgressUpdate, lifted from the Go table literals (golit.py)
+                          TestLeaderAppResp, TestLeaderIncreaseNext and TestProgressUpdate, lifted from the Go table literals (golit.py)
   progress_tables.json    every table and imperative case of tracker/progress_test.go and
                           tracker/inflights_test.go, lifted the same way
   figure7.json            the leader's side of testdata/probe_and_replicate.txt, line by line
@@ -236,6 +236,18 @@ def make_tables():
         "peers": [int(x) for x in peers.group(1).split(",")], "from": int(frm.group(1)),
         "log": [[e["Index"], e["Term"]] for e in ents[1:]],
         "rows": [{k: (int(v) if not isinstance(v, bool) else v) for k, v in r.items()} for r in rows]}
+    # bcastAppend after a proposal (raft.go:1276-1310 -> :689-696 -> maybeSendAppend :600-666 -> UpdateOnEntriesSend,
+    # tracker/progress.go:141-166): a 2-peer leader with `previousEnts` + becomeLeader's empty entry, Progress[2] forced
+    # to (state, next), one proposal; expected Progress[2].Next afterwards
+    body, a, b = golit.func_source(_go("raft_test.go"), "TestLeaderIncreaseNext")
+    p0 = body.index("[]pb.Entry{", body.index("previousEnts :="))
+    prev = golit.parse_expr(body[p0:golit.match_brace(body, body.index("{", p0)) + 1])
+    rows = golit.struct_table(body.replace("len(previousEnts)", str(len(prev))),
+                              env={"tracker.StateProbe": 0, "tracker.StateReplicate": 1, "tracker.StateSnapshot": 2})
+    peers = re.search(r"withPeers\(([^)]*)\)", body)
+    assert len(re.findall(r"Type: pb\.MsgProp", body)) == 1 and len(rows) == 2, rows
+    out["TestLeaderIncreaseNext"] = {"src": _src("raft_test.go", a, b), "peers": [int(x) for x in peers.group(1).split(",")],
+                                     "log": [[e["Index"], e["Term"]] for e in prev], "rows": rows}
     upd = progress_update_table()
     out["TestProgressUpdate"] = {"src": upd["src"], "prevM": upd["prev_match"], "prevN": upd["prev_next"], "rows": upd["rows"]}
     return out

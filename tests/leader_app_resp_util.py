@@ -77,3 +77,31 @@ def replay_row(t, row, drv):
     for to, prev, commit in sent:
         assert prev == row["windex"] and commit == row["wcommitted"], (row, sent)
     return sent
+
+
+def load_increase_next():
+    t = gu.load_tables()["TestLeaderIncreaseNext"]
+    assert len(t["rows"]) == 2
+    return t
+
+
+def replay_increase_next(t, row, drv):
+    """raft_test.go:2760-2790 TestLeaderIncreaseNext: after one proposal the leader's bcastAppend leaves
+    Progress[2].Next at last + 1 in StateReplicate (optimistic) and where it was in StateProbe."""
+    me, peer = t["peers"]
+    last, term = t["log"][-1][0], 1
+    drv.become_leader(me, last, t["log"][0][0], 0, term)
+    for _ in range(2):  # becomeLeader's empty entry, then the proposal (raft.go:787-819 appendEntry)
+        last += 1
+        assert drv.step("appended", me, index=last) == 0
+        assert drv.step("app_resp", me, index=last) & po.ACT_UPDATED
+        if last == t["log"][-1][0] + 1:
+            drv.set_progress(peer, row["state"], row["next"])
+    assert drv.maybe_commit() == 0  # two peers, one has nothing: no quorum
+    plan = drv.plan(peer)  # bcastAppend -> maybeSendAppend(peer, true)
+    assert plan == po.SEND_APPEND
+    nxt = drv.progress(peer)["next"]
+    assert nxt == row["next"]
+    n = last - nxt + 1
+    drv.step("sent_app", peer, entries=n, index=nxt - 1 + n, nbytes=n)
+    assert drv.progress(peer)["next"] == row["wnext"], (row, drv.progress(peer))

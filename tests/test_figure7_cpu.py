@@ -61,6 +61,11 @@ class OracleDriver:
                                     np.array([aux], dtype=np.uint64))
         return int(act[0])
 
+    def set_progress(self, who, state, nxt):
+        """sm.trk.Progress[who].State / .Next = ... as the reference's tests do by hand."""
+        self.pl["pstate"][self.slot[who], 0] = state
+        self.pl["next"][self.slot[who], 0] = nxt
+
     def progress(self, who):
         return pu.cell_state(self.pl, self.cap, 0, self.slot[who], 0)
 

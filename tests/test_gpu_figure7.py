@@ -102,6 +102,14 @@ class EngineDriver:
         msgs["type"] = capi.MSG_APP_RESP
         return self.same(e.step_progress(msgs, np.full(G, resolved, dtype=np.uint64)))
 
+    def set_progress(self, who, state, nxt):
+        """sm.trk.Progress[who].State / .Next = ... as the reference's tests do by hand."""
+        got = self.e.read_progress(rings=False)
+        s = self.slots(who)
+        got["pstate"][s, np.arange(self.G)] = state
+        got["next"][s, np.arange(self.G)] = nxt
+        self.e.upload_progress(got["pstate"], got["next"], got["pending"])
+
     def progress(self, who):
         got = self.e.read_progress(rings=False)
         got["match"] = self.e.read_match()

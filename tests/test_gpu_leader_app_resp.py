@@ -17,3 +17,12 @@ def test_leader_app_resp_table_on_the_engine(G):
     for row in t["rows"]:
         with raft_amd.Engine(G, len(fx["voters"])) as e:
             lar.replay_row(t, row, EngineDriver(e, fx, G, 256))
+
+
+@pytest.mark.parametrize("G", [1, 130])
+def test_leader_increase_next_table_on_the_engine(G):
+    t = lar.load_increase_next()
+    fx = lar.fixture_for_driver(t)
+    for row in t["rows"]:
+        with raft_amd.Engine(G, len(fx["voters"])) as e:
+            lar.replay_increase_next(t, row, EngineDriver(e, fx, G, 256))
