@@ -9,7 +9,7 @@ Writes, into tests/golden/:
   quorum_datadriven.json  the 127 datadriven cases of quorum/testdata/{majority_commit,joint_commit,
                           majority_vote,joint_vote}.txt
   tables.json             the tables of TestCommit, TestLeaderAcknowledgeCommit, TestFindConflictByTerm,
-                          TestLeaderAppResp, TestLeaderIncreaseNext and TestProgressUpdate, lifted from the Go table literals (golit.py)
+                          TestLeaderAppResp, TestLeaderIncreaseNext, TestLeaderElectionInOneRoundRPC and TestProgressUpdate, lifted from the Go table literals (golit.py)
   progress_tables.json    every table and imperative case of tracker/progress_test.go and
                           tracker/inflights_test.go, lifted the same way
   figure7.json            the leader's side of testdata/probe_and_replicate.txt, line by line
@@ -248,6 +248,16 @@ def make_tables():
     assert len(re.findall(r"Type: pb\.MsgProp", body)) == 1 and len(rows) == 2, rows
     out["TestLeaderIncreaseNext"] = {"src": _src("raft_test.go", a, b), "peers": [int(x) for x in peers.group(1).split(",")],
                                      "log": [[e["Index"], e["Term"]] for e in prev], "rows": rows}
+    # raft.poll -> TallyVotes -> VoteResult (raft.go:1041-1049, :1650-1662): a candidate (id 1, votes for itself) in a
+    # cluster of `size` receives the MsgVoteResp of `votes` (id -> granted); the role it ends in is the tally's verdict
+    # (StateLeader = VoteWon, StateFollower = VoteLost, StateCandidate = VotePending)
+    body, a, b = golit.func_source(_go("raft_paper_test.go"), "TestLeaderElectionInOneRoundRPC")
+    rows = golit.struct_table(body)
+    assert len(rows) == 13 and {r["state"] for r in rows} == {"StateLeader", "StateFollower", "StateCandidate"}, rows
+    out["TestLeaderElectionInOneRoundRPC"] = {
+        "src": _src("raft_paper_test.go", a, b),
+        "rows": [{"size": r["size"], "votes": sorted([int(k), bool(v)] for k, v in (r["votes"] or {}).items()),
+                  "state": r["state"]} for r in rows]}
     upd = progress_update_table()
     out["TestProgressUpdate"] = {"src": upd["src"], "prevM": upd["prev_match"], "prevN": upd["prev_next"], "rows": upd["rows"]}
     return out
