@@ -282,6 +282,17 @@ def raftlog_maybe_commit(first_index, snap_term, terms, committed, max_index, te
     return bool(ok), c.value
 
 
+def raftlog_term(first_index, snap_term, terms, i):
+    """raftLog.term(i) (log.go:381-407) -> (term, err) with err 0 ok / 1 ErrCompacted / 2 ErrUnavailable."""
+    t = np.ascontiguousarray(np.asarray(terms, dtype=np.uint64))
+    err = C.c_int()
+    f = lib().oracle_raftlog_term
+    f.restype = C.c_uint64
+    f.argtypes = [C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), C.c_uint64, C.c_uint64, C.POINTER(C.c_int)]
+    term = f(first_index, snap_term, t.ctypes.data_as(C.POINTER(C.c_uint64)), len(t), i, C.byref(err))
+    return int(term), err.value
+
+
 def find_conflict_by_term(first_index, snap_term, terms, index, term):
     """raftLog.findConflictByTerm(index, term) on an explicit log -> (guess index, its term or 0)."""
     t = np.ascontiguousarray(np.asarray(terms, dtype=np.uint64))

@@ -580,12 +580,25 @@ typedef struct {
 
 /* log.go:381-407 — raftLog.term, wrapped in zeroTermOnOutOfBounds (log.go:559-568):
  * ErrCompacted and ErrUnavailable become term 0. */
-static uint64_t log_term_or_zero(const oracle_log *l, uint64_t i) {
+static uint64_t log_term(const oracle_log *l, uint64_t i, int *err) {
     uint64_t last = l->first_index + l->n - 1; /* lastIndex(); first_index-1 when empty */
-    if (i + 1 < l->first_index) return 0;      /* ErrCompacted */
-    if (i > last) return 0;                    /* ErrUnavailable */
+    *err = 0;
+    if (i + 1 < l->first_index) { *err = 1; return 0; } /* ErrCompacted (log.go:383-386) */
+    if (i > last) { *err = 2; return 0; }               /* ErrUnavailable (log.go:387-389) */
     if (i + 1 == l->first_index) return l->snap_term;
     return l->terms[i - l->first_index];
+}
+static uint64_t log_term_or_zero(const oracle_log *l, uint64_t i) {
+    int err;
+    return log_term(l, i, &err);
+}
+
+/* raftLog.term itself (log.go:381-407), for the reference's own table (log_test.go:830-858 TestTerm):
+ * *err = 0 ok, 1 ErrCompacted, 2 ErrUnavailable. */
+ORACLE_API uint64_t oracle_raftlog_term(uint64_t first_index, uint64_t snap_term, const uint64_t *terms,
+                                        uint64_t n, uint64_t i, int *err) {
+    oracle_log l = {first_index, snap_term, terms, n};
+    return log_term(&l, i, err);
 }
 
 /* log.go:447-456 — raftLog.maybeCommit; commitTo (log.go:318-326) never

@@ -3,7 +3,7 @@ expression and composite-literal syntax to lift test tables out of *_test.go fil
 so that no fixture value has to be typed by hand (tests/golden/make_golden.py).
 
 Only syntax is handled, nothing is executed: integer / bool / string literals, identifiers
-(looked up in an environment, else kept as their name), + - *, conversions such as uint64(x),
+(looked up in an environment, else kept as their name), + - * /, conversions such as uint64(x),
 calls (kept as {"call": name, "args": [...]}), composite literals with or without a type
 (keyed -> dict, positional -> list), slices, maps, nil.
 """
@@ -14,7 +14,7 @@ TOKEN = re.compile(r"""
   | (?P<num>0[xX][0-9a-fA-F]+|\d+)
   | (?P<str>"(?:[^"\\]|\\.)*"|`[^`]*`)
   | (?P<id>[A-Za-z_][A-Za-z0-9_]*(?:\.[A-Za-z_][A-Za-z0-9_]*)*)
-  | (?P<op>:=|\.\.\.|[{}()\[\],:&+\-*=<>!;])
+  | (?P<op>:=|\.\.\.|[{}()\[\],:&+\-*/=<>!;])
 """, re.X | re.S)
 
 CONVERSIONS = {"uint64", "int", "int64", "uint32", "uint8", "StateType", "Index"}
@@ -85,9 +85,11 @@ class Parser:
 
     def term(self):
         v = self.unary()
-        while self.peek()[1] == "*":
-            self.take()
-            v = v * self.unary()
+        while self.peek()[1] in ("*", "/"):
+            if self.take() == "*":
+                v = v * self.unary()
+            else:
+                v = v // self.unary()  # Go's integer division (operands here are unsigned)
         return v
 
     def unary(self):

@@ -9,7 +9,8 @@ Writes, into tests/golden/:
   quorum_datadriven.json  the 127 datadriven cases of quorum/testdata/{majority_commit,joint_commit,
                           majority_vote,joint_vote}.txt
   tables.json             the tables of TestCommit, TestLeaderAcknowledgeCommit, TestFindConflictByTerm,
-                          TestLeaderAppResp, TestLeaderIncreaseNext, TestLeaderElectionInOneRoundRPC and TestProgressUpdate, lifted from the Go table literals (golit.py)
+                          TestLeaderAppResp, TestLeaderIncreaseNext, TestLeaderElectionInOneRoundRPC,
+                          TestLeaderOnlyCommitsLogFromCurrentTerm, TestTerm and TestProgressUpdate, lifted from the Go table literals (golit.py)
   progress_tables.json    every table and imperative case of tracker/progress_test.go and
                           tracker/inflights_test.go, lifted the same way
   figure7.json            the leader's side of testdata/probe_and_replicate.txt, line by line
@@ -258,6 +259,25 @@ def make_tables():
         "src": _src("raft_paper_test.go", a, b),
         "rows": [{"size": r["size"], "votes": sorted([int(k), bool(v)] for k, v in (r["votes"] or {}).items()),
                   "state": r["state"]} for r in rows]}
+    # raftLog.maybeCommit's term guard through the leader (log.go:447-456 via raft.go:755-758; Raft paper 5.4.2): a
+    # 2-peer leader at term 3 over a log of earlier terms appends its empty entry and one proposal; peer 2 acknowledges
+    # `index`; expected raftLog.committed
+    body, a, b = golit.func_source(_go("raft_paper_test.go"), "TestLeaderOnlyCommitsLogFromCurrentTerm")
+    p0 = body.index("[]pb.Entry{", body.index("ents :="))
+    ents = golit.parse_expr(body[p0:golit.match_brace(body, body.index("{", p0)) + 1])
+    hs = re.search(r"loadState\(pb\.HardState\{Term: (\d+)\}\)", body)
+    assert len(re.findall(r"Type: pb\.MsgProp", body)) == 1 and hs
+    out["TestLeaderOnlyCommitsLogFromCurrentTerm"] = {
+        "src": _src("raft_paper_test.go", a, b), "peers": [int(x) for x in re.search(r"withPeers\(([^)]*)\)", body).group(1).split(",")],
+        "log": [[e["Index"], e["Term"]] for e in ents], "term_before_campaign": int(hs.group(1)),
+        "rows": golit.struct_table(body)}
+    # raftLog.term (log.go:381-407): a log whose snapshot sits at `offset` (term 1) followed by entries offset+i of term
+    # i for i in [1, num); term(idx) -> (term, error)
+    body, a, b = golit.func_source(_go("log_test.go"), "TestTerm")
+    env = {k: int(re.search(r"%s := uint64\((\d+)\)" % k, body).group(1)) for k in ("offset", "num")}
+    rows = golit.struct_table(body, env=env)
+    out["TestTerm"] = {"src": _src("log_test.go", a, b), "offset": env["offset"], "num": env["num"],
+                       "rows": [{"idx": r["idx"], "term": r["term"] or 0, "err": r["err"]} for r in rows]}
     upd = progress_update_table()
     out["TestProgressUpdate"] = {"src": upd["src"], "prevM": upd["prev_match"], "prevN": upd["prev_next"], "rows": upd["rows"]}
     return out

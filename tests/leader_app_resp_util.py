@@ -105,3 +105,25 @@ def replay_increase_next(t, row, drv):
     n = last - nxt + 1
     drv.step("sent_app", peer, entries=n, index=nxt - 1 + n, nbytes=n)
     assert drv.progress(peer)["next"] == row["wnext"], (row, drv.progress(peer))
+
+
+def load_current_term_commit():
+    t = gu.load_tables()["TestLeaderOnlyCommitsLogFromCurrentTerm"]
+    assert len(t["rows"]) == 3
+    return t
+
+
+def replay_current_term_commit(t, row, drv):
+    """raft_paper_test.go:871-901 TestLeaderOnlyCommitsLogFromCurrentTerm: a quorum index whose entry carries an
+    earlier term does not move raftLog.committed (log.go:447-456); one of the leader's own term does."""
+    me, peer = t["peers"]
+    last = t["log"][-1][0]
+    term = t["term_before_campaign"] + 1  # becomeCandidate (raft.go:887-899)
+    drv.become_leader(me, last, t["log"][0][0], 0, term)
+    for _ in range(2):  # becomeLeader's empty entry, then the proposal
+        last += 1
+        assert drv.step("appended", me, index=last) == 0
+        assert drv.step("app_resp", me, index=last) & po.ACT_UPDATED
+    assert drv.maybe_commit() == 0
+    drv.step("app_resp", peer, index=row["index"])
+    assert drv.maybe_commit() == row["wcommit"], row

@@ -26,3 +26,13 @@ def test_leader_increase_next_table_on_the_engine(G):
     for row in t["rows"]:
         with raft_amd.Engine(G, len(fx["voters"])) as e:
             lar.replay_increase_next(t, row, EngineDriver(e, fx, G, 256))
+
+
+@pytest.mark.parametrize("G", [1, 200])
+def test_leader_only_commits_log_from_current_term_on_the_engine(G):
+    """The term guard of rafthip_commit_advance against raft_paper_test.go:871-901."""
+    t = lar.load_current_term_commit()
+    fx = lar.fixture_for_driver(t)
+    for row in t["rows"]:
+        with raft_amd.Engine(G, len(fx["voters"])) as e:
+            lar.replay_current_term_commit(t, row, EngineDriver(e, fx, G, 256))
