@@ -601,10 +601,14 @@ def main():
         if rank == 0:
             full = np.full(G_BATCH, (1 << VOTERS) - 1, dtype=np.uint8)
             one = raft_amd.batch_committed_index(first_match, full, device=local_rank)
-            a = time.perf_counter()
-            for _ in range(10):  # a tick loop keeps its result slice
-                raft_amd.batch_committed_index(first_match, full, device=local_rank, out=one)
-            extra["oneshot_host_buffers_groups_per_s"] = 10 * G_BATCH / (time.perf_counter() - a)
+            rounds = []
+            for _ in range(5):  # five rounds of ten calls, the median round reported: the host side of this call
+                a = time.perf_counter()  # (staging threads, page-locked copies) shares the box with other tenants
+                for _ in range(10):  # a tick loop keeps its result slice
+                    raft_amd.batch_committed_index(first_match, full, device=local_rank, out=one)
+                rounds.append(time.perf_counter() - a)
+            extra["oneshot_host_buffers_groups_per_s"] = 10 * G_BATCH / sorted(rounds)[2]
+            extra["oneshot_rounds_groups_per_s"] = [round(10 * G_BATCH / r) for r in rounds]
             a = time.perf_counter()
             for _ in range(5):   # a fresh result array per call: its first-touch page faults are in the figure
                 one = raft_amd.batch_committed_index(first_match, full, device=local_rank)
