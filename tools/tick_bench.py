@@ -121,7 +121,16 @@ def main():
         out_d = {k: round(float(np.median(v)), 3) for k, v in times_d.items()}
         out = {k: round(float(np.median(v)), 3) for k, v in times.items()}
         tick = sum(out.values())
-        print(json.dumps({"groups": G, "slots": S, "messages": N, "bytes_per_message": round(len(data) / N, 1),
+        # what an in-workgroup sort by Progress cell could coalesce ("Why K8/K9 got no LDS pre-sort"):
+        # events that share their cell with an earlier event of the same 256-event window
+        cells = (slots.astype(np.int64) * G + groups.astype(np.int64))[: (N // 256) * 256].reshape(-1, 256)
+        srt = np.sort(cells, axis=1)
+        repeats = int((srt[:, 1:] == srt[:, :-1]).sum())
+        lines = (cells >> 1)  # two 32-byte Progress records per 64-byte line: events that share a LINE within a window
+        srt = np.sort(lines, axis=1)
+        line_repeats = int((srt[:, 1:] == srt[:, :-1]).sum())
+        print(json.dumps({"groups": G, "slots": S, "messages": N,
+                          "events_sharing_a_cell_within_256": repeats, "events_sharing_a_record_line_within_256": line_repeats, "bytes_per_message": round(len(data) / N, 1),
                           "stage_ms": out, "tick_ms": round(tick, 3), "messages_per_s": N / tick * 1e3,
                           "groups_advanced": int(advanced), "applied": int((d_status == 0).sum().item()),
                           "updated": int(((d_act & 2) != 0).sum().item()),
