@@ -59,6 +59,7 @@ extern "C" {
 #define RAFTHIP_ENODEV (-19) /* no such GPU / not a usable HIP device */
 #define RAFTHIP_EIO (-5)     /* a HIP runtime call failed; see rafthip_last_error */
 #define RAFTHIP_ERANGE (-34) /* group range outside [0, num_groups) */
+#define RAFTHIP_EBUSY (-16)  /* a shared resource is held by an overlapping call (rafthip_commit_changed_static) */
 
 /* quorum.VoteResult — quorum/quorum.go:48-58 (0 is not a valid result) */
 #define RAFTHIP_VOTE_PENDING 1
@@ -521,8 +522,10 @@ int rafthip_commit_advance(rafthip_engine *e, rafthip_commit_pair *dst, uint64_t
                            uint64_t *n_advanced);
 int rafthip_read_commit(rafthip_engine *e, uint64_t first, uint64_t count, uint64_t *dst);
 
-/* rafthip_commit_changed for callers that cannot allocate device memory: code
- * under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.
+/* rafthip_commit_changed for callers that cannot allocate device memory: tight
+ * serving loops, harnesses that forbid hipMalloc.  (Not for use inside a HIP graph
+ * capture: like rafthip_commit_changed it waits for the GPU before it returns, and
+ * a wait on a capturing stream invalidates the capture.)
  * No counterpart in the reference.  Same pass and same result as
  * rafthip_commit_changed, but its scratch (ballot words, per-tile counts, the
  * total) lives in a static device array of the library — 2.3 MiB per GPU, held
@@ -532,8 +535,10 @@ int rafthip_read_commit(rafthip_engine *e, uint64_t first, uint64_t count, uint6
  * device memory or page-locked host memory (rafthip_host_alloc), written by the
  * kernel itself; a config must have been set (rafthip_set_uniform_config with
  * voters >= 1, or rafthip_upload_config).  Every call on one GPU shares that
- * GPU's array: calls that overlap on one GPU (two engines, two threads) race;
- * serialise them.  Waits for the GPU like rafthip_commit_changed. */
+ * GPU's array, which one call holds from its first kernel to its final wait: a call
+ * that overlaps another on the same GPU (two engines, two threads) returns
+ * RAFTHIP_EBUSY and does nothing; serialise them.  Waits for the GPU like
+ * rafthip_commit_changed. */
 #define RAFTHIP_STATIC_MAX_GROUPS (1ull << 24)
 int rafthip_commit_changed_static(rafthip_engine *e, rafthip_commit_pair *dst, uint64_t max_pairs,
                                   uint64_t *n_changed);

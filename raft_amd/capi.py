@@ -723,6 +723,99 @@ class Comm:
         return out, width.value
 
 
+class CommSet:
+    """All n ranks of one communicator driven by one thread (rafthip_commit_allgather_many /
+    _dense_many).  `CommSet.loopback(engines, group_bases)` builds the ranks on ONE GPU through the
+    library's internal loopback transport (raft_amd/csrc/rafthip_internal.h — a test seam, not part of
+    include/rafthip.h): the exchange code is the shipped one, only the gather is device copies."""
+
+    def __init__(self, handles, engines):
+        self._L = load_library()
+        self._hs = list(handles)
+        self.engines = list(engines)
+        self.n = len(self._hs)
+        self._arr = (C.c_void_p * self.n)(*self._hs)
+        r, n, cap = C.c_int(), C.c_int(), C.c_uint64()
+        self.caps = []
+        for h in self._hs:
+            _check(self._L.rafthip_comm_info(h, C.byref(r), C.byref(n), C.byref(cap)))
+            assert n.value == self.n
+            self.caps.append(cap.value)
+        self.max_pairs_per_rank = self.caps[0]
+
+    @classmethod
+    def loopback(cls, engines, group_bases, max_pairs_per_rank=None):
+        L = load_library()
+        fn = L.rafthip_internal_comm_create_loopback
+        fn.restype = C.c_int
+        fn.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_void_p)]
+        n = len(engines)
+        earr = (C.c_void_p * n)(*[e._h for e in engines])
+        barr = (C.c_uint64 * n)(*[int(b) for b in group_bases])
+        marr = None if max_pairs_per_rank is None else (C.c_uint64 * n)(*[int(m) for m in max_pairs_per_rank])
+        out = (C.c_void_p * n)()
+        _check(fn(earr, n, barr, marr, out))
+        return cls([C.c_void_p(h) for h in out], engines)
+
+    def close(self):
+        for h in getattr(self, "_hs", []):
+            self._L.rafthip_comm_destroy(h)
+        self._hs = []
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def commit_allgather(self, advance=False, max_pairs=None, dsts=None):
+        """The exchange on every rank.  Returns (per rank: gathered pairs as numpy PAIR_DTYPE — or None when
+        `dsts` (addresses) were given —, per rank: counts[nranks], per rank: total)."""
+        n = self.n
+        if max_pairs is None:
+            max_pairs = [n * self.max_pairs_per_rank] * n
+        elif np.isscalar(max_pairs):
+            max_pairs = [int(max_pairs)] * n
+        outs = None
+        if dsts is None:
+            outs = [np.empty(m, dtype=PAIR_DTYPE) for m in max_pairs]
+            dsts = [o.ctypes.data if m else None for o, m in zip(outs, max_pairs)]
+        counts = [np.zeros(n, dtype=np.uint64) for _ in range(n)]
+        darr = (C.c_void_p * n)(*dsts)
+        marr = (C.c_uint64 * n)(*max_pairs)
+        carr = (C.c_void_p * n)(*[c.ctypes.data for c in counts])
+        totals = (C.c_uint64 * n)()
+        _check(self._L.rafthip_commit_allgather_many(self._arr, n, int(bool(advance)), darr, marr, carr, totals))
+        if outs is not None:
+            outs = [o[:min(int(np.minimum(c, self.max_pairs_per_rank).sum()), m)] for o, c, m in zip(outs, counts, max_pairs)]
+        return outs, counts, [int(t) for t in totals]
+
+    def dense_width(self):
+        w = (C.c_uint64 * self.n)()
+        _check(self._L.rafthip_commit_allgather_dense_many(self._arr, self.n, 0, None, None, w))
+        return int(w[0])
+
+    def commit_allgather_dense(self, advance=False, dsts=None, dst_elems=None):
+        """The dense exchange on every rank.  Returns (per rank: planes [nranks][width] or None with `dsts`, width)."""
+        n = self.n
+        width = self.dense_width()
+        outs = None
+        if dsts is None:
+            outs = [np.empty(n * width, dtype=np.uint64) for _ in range(n)]
+            dsts = [o.ctypes.data for o in outs]
+            dst_elems = [n * width] * n
+        darr = (C.c_void_p * n)(*dsts)
+        earr = (C.c_uint64 * n)(*dst_elems)
+        w = (C.c_uint64 * n)()
+        _check(self._L.rafthip_commit_allgather_dense_many(self._arr, n, int(bool(advance)), darr, earr, w))
+        assert all(int(x) == width for x in w)
+        if outs is not None:
+            outs = [o.reshape(n, width) for o in outs]
+        return outs, width
+
+
 def batch_committed_index(match, in_mask, out_mask=None, device=0, out=None):
     """quorum.BatchCommittedIndex: match u64 [S][G], slot masks [G] → u64 [G] (`out`: a result array to reuse)."""
     S, G = match.shape

@@ -24,6 +24,7 @@
 #include "progress.h"
 #include "wire.h"
 #include "rafthip.h"
+#include "rafthip_internal.h"
 
 using namespace rafthip;
 
@@ -87,6 +88,10 @@ namespace {
 constexpr int kMaxDevices = 64;
 std::mutex g_scratch_mu;
 void* g_scratch_ptr[kMaxDevices] = {};
+// One holder of a device's scratch array at a time, from the first kernel that writes it to the wait
+// that ends the call (rafthip_commit_changed_static): an overlapping call on the same GPU fails with
+// RAFTHIP_EBUSY instead of returning pairs built from another call's ballot words.
+std::mutex g_scratch_busy[kMaxDevices];
 
 // Address of this device's copy of `scratch` (device must be current).  Resolved
 // on the first rafthip_create on a device; later calls only read the table.
@@ -1808,6 +1813,10 @@ int rafthip_commit_many(rafthip_engine* const* engines, uint32_t n) {
             if (engines[i]->stream == st) continue;
             hipError_t err = hipStreamQuery(engines[i]->stream);  // an idle stream has nothing to wait for
             if (err == hipSuccess) continue;
+            if (err != hipErrorNotReady) {
+                (void)hipEventDestroy(ev);
+                return fail(RAFTHIP_EIO, "hipStreamQuery: %s", hipGetErrorString(err));
+            }
             (void)hipGetLastError();
             err = hipEventRecord(ev, engines[i]->stream);
             if (err == hipSuccess) err = hipStreamWaitEvent(st, ev, 0);
@@ -2033,6 +2042,10 @@ int rafthip_commit_changed_static(rafthip_engine* e, rafthip_commit_pair* dst, u
     void* base = nullptr;
     int rc = static_scratch(e->device, &base);  // resolved by rafthip_create: a table read
     if (rc) return rc;
+    std::unique_lock<std::mutex> busy(g_scratch_busy[e->device], std::try_to_lock);
+    if (!busy.owns_lock())
+        return fail(RAFTHIP_EBUSY, "rafthip_commit_changed_static: another call is using device %d's scratch array "
+                                   "(calls on one GPU share it: serialise them)", e->device);
     unsigned char* p = static_cast<unsigned char*>(base);
     ReportBufs rb;
     rb.bits = reinterpret_cast<u64*>(p);
@@ -2354,9 +2367,23 @@ int rafthip_plane(rafthip_engine* e, int which, void** ptr, uint64_t* stride) {
 // ---- C1: the exchange step over RCCL ------------------------------------------
 }  // extern "C"
 
+struct rafthip_comm;
+// The loopback transport (rafthip_internal.h): n engines on ONE GPU stand for n ranks, and an
+// all-gather is n x n device copies ordered with events.  Everything around the gather — the
+// reporting pass with group_base, the speculative width and its redo, k_pack_gathered, clipping
+// at cap, the landing buffers, the dense form — is the code the RCCL transport runs.
+struct LoopGroup {
+    int n = 0;
+    int refs = 0;
+    rafthip_comm* member[64] = {};
+    hipEvent_t ready[64] = {};  // rank r's send buffer is complete on its stream
+    hipEvent_t done[64] = {};   // rank i has copied every rank's contribution
+};
+
 struct rafthip_comm {
     rafthip_engine* e = nullptr;
     ncclComm_t nccl = nullptr;
+    LoopGroup* loop = nullptr;  // set instead of nccl for a loopback communicator
     int rank = 0, nranks = 1;
     u64 group_base = 0;
     u64 cap = 0;             // pairs per rank, equal on every rank
@@ -2388,6 +2415,17 @@ void comm_free(rafthip_comm* c) {
         DeviceGuard guard(c->e->device);
         if (c->e->stream) (void)hipStreamSynchronize(c->e->stream);
         if (c->nccl) (void)ncclCommDestroy(c->nccl);
+        if (c->loop) {
+            LoopGroup* g = c->loop;
+            if (c->rank >= 0 && c->rank < g->n) g->member[c->rank] = nullptr;
+            if (--g->refs == 0) {
+                for (int r = 0; r < g->n; ++r) {
+                    if (g->ready[r]) (void)hipEventDestroy(g->ready[r]);
+                    if (g->done[r]) (void)hipEventDestroy(g->done[r]);
+                }
+                delete g;
+            }
+        }
         for (void* b : {(void*)c->d_send, (void*)c->d_counts, (void*)c->d_recv, (void*)c->d_out, (void*)c->d_plane_send,
                         (void*)c->d_plane_recv})
             if (b) (void)hipFree(b);
@@ -2427,9 +2465,67 @@ int enqueue_pack_gathered(rafthip_comm* c, u64 width, Pair* out, u64 max_pairs) 
     return RAFTHIP_OK;
 }
 
+// ---- the one indirection under every collective of this file ---------------------------------
+// An all-gather of `count` uint64 words per rank on each comms[i] (the ranks this thread drives),
+// enqueued on the engines' streams.  RCCL: one ncclAllGather per rank, inside one RCCL group when
+// there are several; the group is always closed, and the first error is what comes back (a failed
+// exchange leaves the communicator unusable: destroy it and create a new one — the peers of a rank
+// that failed here are still inside the collective).  Loopback: device copies ordered with events.
+struct GatherArgs {
+    const void* send;
+    void* recv;
+    size_t count;
+};
+
+int loop_all_gather(rafthip_comm** comms, int n, const GatherArgs* a) {
+    LoopGroup* g = comms[0]->loop;
+    if (n != g->n) return fail(RAFTHIP_EINVAL, "loopback exchange: %d of %d ranks in the call (all of them run in one thread)", n, g->n);
+    for (int i = 0; i < n; ++i) {
+        if (comms[i]->loop != g || comms[i]->rank != i) return fail(RAFTHIP_EINVAL, "loopback exchange: comms[%d] is not rank %d of the group", i, i);
+        if (a[i].count != a[0].count) return fail(RAFTHIP_EINVAL, "loopback exchange: ranks disagree on the element count");
+    }
+    const size_t bytes = a[0].count * sizeof(u64);
+    if (bytes == 0) return RAFTHIP_OK;
+    DeviceGuard guard(comms[0]->e->device);
+    for (int r = 0; r < n; ++r) HIP_TRY(hipEventRecord(g->ready[r], comms[r]->e->stream));
+    for (int i = 0; i < n; ++i) {
+        hipStream_t st = comms[i]->e->stream;
+        for (int r = 0; r < n; ++r) {
+            if (r != i) HIP_TRY(hipStreamWaitEvent(st, g->ready[r], 0));
+            void* d = static_cast<char*>(a[i].recv) + (size_t)r * bytes;
+            if (d != a[r].send) HIP_TRY(hipMemcpyAsync(d, a[r].send, bytes, hipMemcpyDefault, st));  // in place: own slot already there
+        }
+        HIP_TRY(hipEventRecord(g->done[i], st));
+    }
+    // like the collective it stands for: a rank's send buffer is free again only when every rank has read it
+    for (int r = 0; r < n; ++r)
+        for (int i = 0; i < n; ++i)
+            if (i != r) HIP_TRY(hipStreamWaitEvent(comms[r]->e->stream, g->done[i], 0));
+    return RAFTHIP_OK;
+}
+
+int all_gather_many(rafthip_comm** comms, int n, const GatherArgs* a) {
+    if (comms[0]->loop) return loop_all_gather(comms, n, a);
+    int rc = RAFTHIP_OK;
+    const bool grouped = n > 1;
+    if (grouped) NCCL_TRY(ncclGroupStart());
+    for (int i = 0; i < n; ++i) {
+        rafthip_comm* c = comms[i];
+        DeviceGuard guard(c->e->device);
+        const ncclResult_t r = ncclAllGather(a[i].send, a[i].recv, a[i].count, ncclUint64, c->nccl, c->e->stream);
+        if (r != ncclSuccess && !rc) rc = fail(RAFTHIP_EIO, "ncclAllGather (rank %d): %s", c->rank, ncclGetErrorString(r));
+    }
+    if (grouped) {
+        const ncclResult_t r = ncclGroupEnd();  // always closed, also after a failed call inside it
+        if (r != ncclSuccess && !rc) rc = fail(RAFTHIP_EIO, "ncclGroupEnd: %s", ncclGetErrorString(r));
+    }
+    return rc;
+}
+
 template <int MODE>
 int exchange_many(rafthip_comm** comms, int n, rafthip_commit_pair** dst, const uint64_t* max_pairs,
                   uint64_t** counts_out, uint64_t* n_total) {
+    GatherArgs ga[kMaxDevices];
     // 1. every engine's commit pass: pairs with global ids into its send buffer, count in *rb.total
     ReportBufs rb[kMaxDevices];
     for (int i = 0; i < n; ++i) {
@@ -2440,13 +2536,11 @@ int exchange_many(rafthip_comm** comms, int n, rafthip_commit_pair** dst, const 
         if ((rc = report_pass<MODE>(c->e, rb[i], c->group_base, c->d_send, c->cap))) return rc;
     }
     // 2. counts to every rank
-    if (n > 1) NCCL_TRY(ncclGroupStart());
-    for (int i = 0; i < n; ++i) {
-        rafthip_comm* c = comms[i];
-        DeviceGuard guard(c->e->device);
-        NCCL_TRY(ncclAllGather(rb[i].total, c->d_counts, 1, ncclUint64, c->nccl, c->e->stream));
+    for (int i = 0; i < n; ++i) ga[i] = GatherArgs{rb[i].total, comms[i]->d_counts, 1};
+    {
+        int rc = all_gather_many(comms, n, ga);
+        if (rc) return rc;
     }
-    if (n > 1) NCCL_TRY(ncclGroupEnd());
     for (int i = 0; i < n; ++i) {
         rafthip_comm* c = comms[i];
         DeviceGuard guard(c->e->device);
@@ -2477,13 +2571,9 @@ int exchange_many(rafthip_comm** comms, int n, rafthip_commit_pair** dst, const 
     }
     for (int attempt = 0; attempt < 2; ++attempt) {
         if (width) {
-            if (n > 1) NCCL_TRY(ncclGroupStart());
-            for (int i = 0; i < n; ++i) {
-                rafthip_comm* c = comms[i];
-                DeviceGuard guard(c->e->device);
-                NCCL_TRY(ncclAllGather(c->d_send, c->d_recv, (size_t)width * 2, ncclUint64, c->nccl, c->e->stream));
-            }
-            if (n > 1) NCCL_TRY(ncclGroupEnd());
+            for (int i = 0; i < n; ++i) ga[i] = GatherArgs{comms[i]->d_send, comms[i]->d_recv, (size_t)width * 2};
+            int rc = all_gather_many(comms, n, ga);
+            if (rc) return rc;
         }
         for (int i = 0; i < n; ++i) {
             rafthip_comm* c = comms[i];
@@ -2580,14 +2670,15 @@ int exchange_dense(rafthip_comm** comms, int n, int advance, uint64_t** dst, con
         }
         target[i] = direct;
     }
-    if (n > 1) NCCL_TRY(ncclGroupStart());
+    GatherArgs ga[kMaxDevices];
     for (int i = 0; i < n; ++i) {
-        rafthip_comm* c = comms[i];
-        DeviceGuard guard(c->e->device);
-        const u64* send = c->d_plane_send ? c->d_plane_send : c->e->commit;
-        NCCL_TRY(ncclAllGather(send, target[i], (size_t)c->width, ncclUint64, c->nccl, c->e->stream));
+        const rafthip_comm* c = comms[i];
+        ga[i] = GatherArgs{c->d_plane_send ? c->d_plane_send : c->e->commit, target[i], (size_t)c->width};
     }
-    if (n > 1) NCCL_TRY(ncclGroupEnd());
+    {
+        int rc = all_gather_many(comms, n, ga);
+        if (rc) return rc;
+    }
     for (int i = 0; i < n; ++i) {
         rafthip_comm* c = comms[i];
         DeviceGuard guard(c->e->device);
@@ -2605,8 +2696,32 @@ int exchange_dense(rafthip_comm** comms, int n, int advance, uint64_t** dst, con
 int check_comms(rafthip_comm** comms, int n) {
     if (!comms || n < 1 || n > kMaxDevices) return fail(RAFTHIP_EINVAL, "comms is NULL or n outside [1, %d]", kMaxDevices);
     for (int i = 0; i < n; ++i)
-        if (!comms[i] || !comms[i]->e || !comms[i]->nccl) return fail(RAFTHIP_EINVAL, "comms[%d] is not a live communicator", i);
+        if (!comms[i] || !comms[i]->e || (!comms[i]->nccl && !comms[i]->loop))
+            return fail(RAFTHIP_EINVAL, "comms[%d] is not a live communicator", i);
+    for (int i = 1; i < n; ++i)
+        if ((comms[i]->loop != nullptr) != (comms[0]->loop != nullptr) || comms[i]->nranks != comms[0]->nranks)
+            return fail(RAFTHIP_EINVAL, "comms[%d] and comms[0] belong to different communicators", i);
+    if (comms[0]->loop && n != comms[0]->nranks)
+        return fail(RAFTHIP_EINVAL, "loopback exchange: %d of %d ranks in the call (all of them run in one thread)", n, comms[0]->nranks);
     return RAFTHIP_OK;
+}
+
+// The second half of a communicator's creation, after the in-place all-gather of every rank's two
+// words (pair capacity asked for, plane stride): the capacity every rank uses is the largest one
+// asked for, the dense width the largest plane stride; then the payload buffers.
+int comm_adopt_agreement(rafthip_comm* c) {
+    rafthip_engine* e = c->e;
+    int rc;
+    HIP_TRY(hipMemcpyAsync(c->h_counts, c->d_counts, (size_t)c->nranks * 2 * sizeof(u64), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    for (int k = 0; k < c->nranks; ++k) {
+        c->cap = c->h_counts[2 * k] > c->cap ? c->h_counts[2 * k] : c->cap;
+        c->width = c->h_counts[2 * k + 1] > c->width ? c->h_counts[2 * k + 1] : c->width;
+    }
+    c->cap = round_up(c->cap, kGatherGranule);
+    if (c->width > e->stride && (rc = ensure(e, c->d_plane_send, (size_t)c->width * sizeof(u64)))) return rc;  // zeroed
+    if ((rc = comm_alloc_payload(c))) return rc;
+    return ensure(e, c->d_out, (size_t)c->cap * c->nranks * sizeof(Pair), false);
 }
 
 }  // namespace
@@ -2660,25 +2775,9 @@ int rafthip_comm_create(rafthip_engine* e, const rafthip_comm_id* id, int rank, 
         if ((rc = comm_agree_and_alloc(c, max_pairs_per_rank))) break;
         // the capacity every rank uses = the largest one asked for, the dense width = the largest plane
         // stride: an in-place all-gather of both + max
-        r = ncclAllGather(c->d_counts + 2 * rank, c->d_counts, 2, ncclUint64, c->nccl, e->stream);
-        if (r != ncclSuccess) {
-            rc = fail(RAFTHIP_EIO, "ncclAllGather: %s", ncclGetErrorString(r));
-            break;
-        }
-        hipError_t err = hipMemcpyAsync(c->h_counts, c->d_counts, (size_t)nranks * 2 * sizeof(u64), hipMemcpyDeviceToHost, e->stream);
-        if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
-        if (err != hipSuccess) {
-            rc = fail(RAFTHIP_EIO, "capacity exchange: %s", hipGetErrorString(err));
-            break;
-        }
-        for (int k = 0; k < nranks; ++k) {
-            c->cap = c->h_counts[2 * k] > c->cap ? c->h_counts[2 * k] : c->cap;
-            c->width = c->h_counts[2 * k + 1] > c->width ? c->h_counts[2 * k + 1] : c->width;
-        }
-        c->cap = round_up(c->cap, kGatherGranule);
-        if (c->width > e->stride && (rc = ensure(e, c->d_plane_send, (size_t)c->width * sizeof(u64)))) break;  // zeroed
-        if ((rc = comm_alloc_payload(c))) break;
-        if ((rc = ensure(e, c->d_out, (size_t)c->cap * nranks * sizeof(Pair), false))) break;
+        const GatherArgs ga{c->d_counts + 2 * rank, c->d_counts, 2};
+        if ((rc = all_gather_many(&c, 1, &ga))) break;
+        rc = comm_adopt_agreement(c);
     } while (0);
     if (rc) {
         char keep[sizeof(g_err)];
@@ -2739,6 +2838,72 @@ int rafthip_comm_create_all(rafthip_engine** engines, int n, const uint64_t* gro
         for (int i = 0; i < n; ++i) {
             comm_free(out[i]);
             out[i] = nullptr;
+        }
+        memcpy(g_err, keep, sizeof(keep));
+    }
+    return rc;
+}
+
+// rafthip_internal.h — n engines on ONE GPU as the n ranks of a loopback communicator.  Creation walks
+// the per-process path of rafthip_comm_create rank by rank (each rank's two words, the in-place
+// all-gather, the agreement), not the host-side shortcut of rafthip_comm_create_all.
+int rafthip_internal_comm_create_loopback(rafthip_engine** engines, int n, const uint64_t* group_base,
+                                          const uint64_t* max_pairs_per_rank, rafthip_comm** out) {
+    if (!engines || !out || !group_base) return fail(RAFTHIP_EINVAL, "engines/group_base/out is NULL");
+    if (n < 1 || n > kMaxDevices) return fail(RAFTHIP_EINVAL, "n %d outside [1, %d]", n, kMaxDevices);
+    for (int i = 0; i < n; ++i) {
+        out[i] = nullptr;
+        if (!engines[i]) return fail(RAFTHIP_EINVAL, "engines[%d] is NULL", i);
+        if (engines[i]->device != engines[0]->device) return fail(RAFTHIP_EINVAL, "loopback ranks share one GPU; engines[%d] is on another", i);
+        for (int k = 0; k < i; ++k)
+            if (engines[k] == engines[i]) return fail(RAFTHIP_EINVAL, "engines[%d] and engines[%d] are the same engine", k, i);
+    }
+    DeviceGuard guard(engines[0]->device);
+    LoopGroup* g = new (std::nothrow) LoopGroup();
+    if (!g) return fail(RAFTHIP_ENOMEM, "host allocation failed");
+    g->n = n;
+    int rc = RAFTHIP_OK;
+    for (int i = 0; i < n && !rc; ++i) {
+        hipError_t err = hipEventCreateWithFlags(&g->ready[i], hipEventDisableTiming);
+        if (err == hipSuccess) err = hipEventCreateWithFlags(&g->done[i], hipEventDisableTiming);
+        if (err != hipSuccess) rc = fail(RAFTHIP_EIO, "hipEventCreate: %s", hipGetErrorString(err));
+    }
+    for (int i = 0; i < n && !rc; ++i) {
+        rafthip_comm* c = new (std::nothrow) rafthip_comm();
+        if (!c) {
+            rc = fail(RAFTHIP_ENOMEM, "host allocation failed");
+            break;
+        }
+        out[i] = c;
+        c->e = engines[i];
+        c->loop = g;
+        g->refs++;
+        g->member[i] = c;
+        c->rank = i;
+        c->nranks = n;
+        c->group_base = group_base[i];
+        rc = comm_agree_and_alloc(c, max_pairs_per_rank ? max_pairs_per_rank[i] : 0);
+    }
+    if (!rc) {
+        GatherArgs ga[kMaxDevices];
+        for (int i = 0; i < n; ++i) ga[i] = GatherArgs{out[i]->d_counts + 2 * i, out[i]->d_counts, 2};
+        rc = all_gather_many(out, n, ga);
+    }
+    for (int i = 0; i < n && !rc; ++i) rc = comm_adopt_agreement(out[i]);
+    if (rc) {
+        char keep[sizeof(g_err)];
+        memcpy(keep, g_err, sizeof(keep));
+        const bool orphan = g->refs == 0;
+        for (int i = 0; i < n; ++i) {
+            comm_free(out[i]);
+            out[i] = nullptr;
+        }
+        if (orphan) {
+            for (int r = 0; r < n; ++r) {
+                if (g->ready[r]) (void)hipEventDestroy(g->ready[r]);
+                if (g->done[r]) (void)hipEventDestroy(g->done[r]);
+            }
+            delete g;
         }
         memcpy(g_err, keep, sizeof(keep));
     }
