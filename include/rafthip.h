@@ -380,7 +380,8 @@ int rafthip_upload_progress(rafthip_engine *e, uint64_t first, uint64_t count, c
                             const uint64_t *next, const uint64_t *pending, uint64_t src_stride);
 /* One new peer — Changer.initProgress, confchange/confchange.go:257-270: the row
  * (slot, group) becomes {state, Next = next, PendingSnapshot = pending, empty
- * Inflights}; the reference creates it as StateProbe with Next = max(LastIndex, 1).
+ * Inflights}; the reference creates it as StateProbe with Next = c.LastIndex
+ * (confchange/confchange.go:262; 0 for a peer added to an empty log).
  * The group's other rows keep their state and Inflights (rafthip_upload_progress
  * re-initialises whole groups).  Match is rafthip_upload_match's. */
 int rafthip_init_progress_row(rafthip_engine *e, uint64_t group, uint32_t slot, uint8_t state, uint64_t next,

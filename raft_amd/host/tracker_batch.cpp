@@ -193,10 +193,11 @@ int BatchProgressTracker::SetConfig(uint64_t group, const quorum::MajorityConfig
     touch(rdacks_dirty_, group);
     if (row_dirty && (rc = lib(rafthip_upload_match(e_, group, 1, row.data(), 1)))) return rc;
     if (progress_) {
-        // The slot may have held another peer: {StateProbe, Next max(LastIndex, 1), empty Inflights} for the
-        // new one only (Changer.initProgress, confchange.go:257-270); the surviving peers keep theirs.
+        // The slot may have held another peer: {StateProbe, Next = LastIndex, empty Inflights} for the new one
+        // only (Changer.initProgress, confchange.go:257-270 — `Next: c.LastIndex`, so a peer added at LastIndex 0
+        // starts with Next 0, as confchange/testdata/*.txt print it); the surviving peers keep theirs.
         for (uint32_t s : fresh)
-            if ((rc = lib(rafthip_init_progress_row(e_, group, s, RAFTHIP_STATE_PROBE, last_index > 1 ? last_index : 1, 0))))
+            if ((rc = lib(rafthip_init_progress_row(e_, group, s, RAFTHIP_STATE_PROBE, last_index, 0))))
                 return rc;
     }
     return push_config(group);

@@ -49,7 +49,7 @@ class BatchProgressTracker {
     // their Progress; removed ids lose it; new ids start with Match 0 and
     // RecentActive true (confchange.go:257-270).
     // With EnableProgress, a new id's row is also re-created the way Changer.initProgress
-    // does — StateProbe, Next = max(last_index, 1), empty Inflights — and the rows of the
+    // does — StateProbe, Next = last_index (confchange.go:262), empty Inflights — and the rows of the
     // ids that stay are left alone (last_index = Changer.LastIndex, the leader's last index).
     int SetConfig(uint64_t group, const quorum::MajorityConfig& incoming,
                   const quorum::MajorityConfig& outgoing, const quorum::MajorityConfig& learners,

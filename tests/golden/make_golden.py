@@ -550,6 +550,46 @@ def confchange_shapes():
     return out
 
 
+PROGRESS_LINE = re.compile(r"^(\d+): (State\w+) match=(\d+) next=(\d+)( learner)?")
+
+
+def confchange_init_progress():
+    """Changer.initProgress as the conf-change transcripts print it (confchange/confchange.go:257-270: a new peer's
+    Progress is {Match: 0, Next: c.LastIndex, StateProbe}).  The datadriven harness starts every file at LastIndex 0
+    and increments it after each command, failed ones included (confchange/datadriven_test.go:33-36,48-51), so the
+    k-th command of a file (k from 0) runs with LastIndex k; every Progress line of a peer the file had not printed
+    before is that peer's initProgress.  One record per first appearance: the LastIndex the command ran with and
+    the state / match / next the transcript prints."""
+    out = []
+    d = os.path.join(REF, "confchange", "testdata")
+    for name in sorted(os.listdir(d)):
+        lines = open(os.path.join(d, name), encoding="utf-8").read().split("\n")
+        known, cmd, i = set(), -1, 0
+        while i < len(lines):
+            if lines[i].strip() == "----":  # the line before the separator block is the input; a new command starts here
+                cmd += 1
+                i += 1
+                present = set()
+                while i < len(lines) and lines[i].strip() != "":
+                    m = PROGRESS_LINE.match(lines[i])
+                    if m:
+                        pid = int(m.group(1))
+                        present.add(pid)
+                        if pid not in known:
+                            out.append({"id": pid, "last_index": cmd, "state": m.group(2), "match": int(m.group(3)),
+                                        "next": int(m.group(4)), "learner": bool(m.group(5)),
+                                        "src": "confchange/testdata/%s:%d" % (name, i + 1)})
+                    i += 1
+                if present:  # a failed command prints its error only and changes nothing
+                    known = present  # a removed peer that comes back is initialised again
+                continue
+            i += 1
+    assert len(out) >= 25 and sum(1 for r in out if r["next"] == 0) >= 5, len(out)
+    assert all(r["next"] == r["last_index"] and r["match"] == 0 and r["state"] == "StateProbe" for r in out), \
+        [r for r in out if r["next"] != r["last_index"]][:3]
+    return out
+
+
 def write_json(path, obj):
     with open(path, "w") as fh:
         json.dump(obj, fh, indent=1)
@@ -588,7 +628,12 @@ def generate(out_dir):
                {"_doc": "Every distinct tracker.Config the reference's conf-change transcripts print (incoming && outgoing "
                         "voters, learners, learners_next), with the first line that prints it.  Shapes only: the transcripts "
                         "hold no commit indexes, so these are inputs for the differential tests, not expected outputs.",
-                "configs": confchange_shapes()})
+                "configs": confchange_shapes(),
+                "init_progress_doc": "Changer.initProgress as the same transcripts print it: the Progress line of every peer at "
+                                     "its first appearance, with the LastIndex its command ran with (the harness increments "
+                                     "LastIndex per command, confchange/datadriven_test.go:33-51).  next == last_index in "
+                                     "every record (confchange/confchange.go:262).",
+                "init_progress": confchange_init_progress()})
     return counts
 
 

@@ -480,9 +480,38 @@ def test_tracker_bcast_heartbeat(oracle):
 
 
 @pytest.mark.gpu
+def test_setconfig_new_peer_starts_as_the_reference_transcripts_print_it():
+    """Changer.initProgress (confchange/confchange.go:257-270) against the reference's own output: every first
+    appearance of a peer in confchange/testdata/*.txt (tests/golden/confchange_shapes.json "init_progress", lifted
+    by make_golden.py) gives the LastIndex its command ran with and the Progress line it printed — `next` equals
+    that LastIndex, 0 included (the mirror used to start such a peer at Next 1)."""
+    import json
+    recs = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "confchange_shapes.json")))["init_progress"]
+    assert any(r["last_index"] == 0 for r in recs) and any(r["last_index"] > 0 for r in recs)
+    script = ["tracker %d 3" % len(recs)]
+    for g, r in enumerate(recs):
+        keeper = 1000 + r["id"]  # a peer that is already there, so that the new one is added by a conf change
+        script.append("setconfig %d in=%d out= learners=" % (g, keeper))
+    script.append("progress 2 0")
+    for g, r in enumerate(recs):
+        keeper = 1000 + r["id"]
+        if r["learner"]:
+            script.append("setconfig %d in=%d out= learners=%d last=%d" % (g, keeper, r["id"], r["last_index"]))
+        else:
+            script.append("setconfig %d in=%d,%d out= learners= last=%d" % (g, keeper, r["id"], r["last_index"]))
+        script.append("progressof %d %d" % (g, r["id"]))
+    out = run_cli("\n".join(script) + "\n")
+    assert not [l for l in out if l.startswith("error") or l == "dropped"], out
+    views = [dict(kv.split("=") for kv in l.split()[3:]) for l in out if l.startswith("progressof")]
+    assert len(views) == len(recs)
+    for r, v in zip(recs, views):
+        assert r["state"] == "StateProbe" and (v["state"], v["match"], v["next"]) == ("0", str(r["match"]), str(r["next"])), (r, v)
+
+
+@pytest.mark.gpu
 def test_setconfig_reuses_a_slot_with_a_fresh_progress():
     """A removed peer's slot goes to a new id: the new peer must start as Changer.initProgress creates it
-    (confchange/confchange.go:257-270: StateProbe, Match 0, Next = max(LastIndex, 1), empty Inflights) — not
+    (confchange/confchange.go:257-270: StateProbe, Match 0, Next = LastIndex, empty Inflights) — not
     with the removed peer's StateReplicate, Next and full Inflights — and the surviving peer keeps everything."""
     from oracle import pyoracle as po
     rep = po.STATE_NAMES["StateReplicate"]
