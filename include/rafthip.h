@@ -485,8 +485,11 @@ int rafthip_commit(rafthip_engine *e);
  * each pay a kernel boundary (at 2^20 groups per shard that boundary is a fifth
  * of the pass).  Same results as calling rafthip_commit on each engine
  * (tracker/tracker.go:179-181).  The single launch needs every engine on one
- * GPU with the same uniform config of 1..8 voters (rafthip_set_uniform_config);
- * any other set of engines is served engine by engine.  Runs on engines[0]'s
+ * GPU and either the same uniform config of 1..8 voters in all of them
+ * (rafthip_set_uniform_config), or the same num_slots <= 8 in all of them — then
+ * shards with per-group masks (joint configs while a conf change is in flight,
+ * quorum/joint.go:49-56) and uniform shards share the launch; any other set of
+ * engines is served engine by engine.  Runs on engines[0]'s
  * stream; engines on other streams are joined to it with events, before and
  * after.  Calls on any of the engines must not overlap this one. */
 int rafthip_commit_many(rafthip_engine *const *engines, uint32_t n);
@@ -496,8 +499,9 @@ int rafthip_commit_many(rafthip_engine *const *engines, uint32_t n);
  * buffer (host or device memory; NULL with max_pairs 0 = count only), its room
  * and its count, exactly as in the single-engine calls (consumer: raft.maybeCommit,
  * raft.go:755-758 / raftLog.maybeCommit, log.go:447-456).  Up to 32 engines on one
- * GPU with the same uniform config of 1..8 voters take one commit launch, one pack
- * launch and one wait together; any other set is served engine by engine.  Runs on
+ * GPU with the same uniform config of 1..8 voters, or with the same num_slots <= 8
+ * (masked and uniform shards mixed), take one commit launch, one pack launch and one
+ * wait together; any other set is served engine by engine.  Runs on
  * engines[0]'s stream (streams of the other engines that still hold work are joined
  * to it first); waits for the GPU.  An engine may appear only once. */
 int rafthip_commit_report_many(rafthip_engine *const *engines, uint32_t n, int advance,

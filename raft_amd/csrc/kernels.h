@@ -440,13 +440,11 @@ __global__ __launch_bounds__(kCommitBlock) void k_commit_uniform_many_report(con
 // keys per lane) and 16-bit masks; a uniform config of more than 8 voters
 // (in_mask == NULL) runs here too.
 // ---------------------------------------------------------------------------
-template <int S, typename MaskT, int MODE, int BLOCK, int CH>
-__global__ __launch_bounds__(BLOCK) void k_commit_masked(const u64* __restrict__ match, u64 stride, u64 G,
-                                                         const MaskT* __restrict__ in_mask,
-                                                         const MaskT* __restrict__ out_mask,
-                                                         u32 uniform_voters, u64* __restrict__ commit,
-                                                         LogBounds lb, Report rep) {
-    const u64 base = (u64)blockIdx.x * (BLOCK * 2 * CH) + threadIdx.x * 2;
+// One tile of K2: res[c].v[j] = the joint commit index of group base + c*2*BLOCK + j.
+template <int S, typename MaskT, int BLOCK, int CH>
+__device__ __forceinline__ void masked_tile(const u64* __restrict__ match, u64 stride, const MaskT* __restrict__ in_mask,
+                                            const MaskT* __restrict__ out_mask, u32 uniform_voters, u64 base,
+                                            Vec<u64, 2> (&res)[CH]) {
     Vec<u64, 2> in[CH][S];
     Vec<MaskT, 2> m0[CH], m1[CH];
 #pragma unroll
@@ -471,7 +469,6 @@ __global__ __launch_bounds__(BLOCK) void k_commit_masked(const u64* __restrict__
     // (Both halves from one sort with the membership in the key's low bits — regs_joint_packed — was tried
     // here as well: no gain at 9..16 slots, where the two sorts hide behind the loads, and at <= 8 slots the
     // extra code cost two waves per SIMD of occupancy.  Measured, not kept: profiles/r02_b_kernels.md.)
-    Vec<u64, 2> res[CH];
 #pragma unroll
     for (int c = 0; c < CH; ++c)
 #pragma unroll
@@ -486,7 +483,53 @@ __global__ __launch_bounds__(BLOCK) void k_commit_masked(const u64* __restrict__
             }
             res[c].v[j] = r;
         }
+}
+
+template <int S, typename MaskT, int MODE, int BLOCK, int CH>
+__global__ __launch_bounds__(BLOCK) void k_commit_masked(const u64* __restrict__ match, u64 stride, u64 G,
+                                                         const MaskT* __restrict__ in_mask,
+                                                         const MaskT* __restrict__ out_mask,
+                                                         u32 uniform_voters, u64* __restrict__ commit,
+                                                         LogBounds lb, Report rep) {
+    const u64 base = (u64)blockIdx.x * (BLOCK * 2 * CH) + threadIdx.x * 2;
+    Vec<u64, 2> res[CH];
+    masked_tile<S, MaskT, BLOCK, CH>(match, stride, in_mask, out_mask, uniform_voters, base, res);
     finish_tile<CH, BLOCK, MODE>(res, base, G, commit, lb, rep, blockIdx.x);
+}
+
+// K2m — K2 (S <= 8) over the shards of several engines in one launch: the shards of a host in the middle of
+// a conf change carry per-group masks (joint configs, confchange.go:51-126) and would otherwise fall out of
+// rafthip_commit_many / _report_many to one launch each.  A shard without mask planes (in_mask NULL) is a
+// uniform one: voters = slots [0, uniform_voters).  Same tile shape as K1m, so the same packing pass follows.
+struct ManyMasks {
+    const uint8_t* in_mask[kManyMax];
+    const uint8_t* out_mask[kManyMax];
+    uint8_t uniform_voters[kManyMax];
+};
+
+template <int S>
+__global__ __launch_bounds__(kCommitBlock) void k_commit_masked_many(const ManyShards sh, const ManyMasks mk) {
+    u32 k = 0;
+    for (u32 i = 1; i < sh.n; ++i) k = blockIdx.x >= sh.first_tile[i] ? i : k;
+    u64* __restrict__ commit = sh.commit[k];
+    const u64 base = (u64)(blockIdx.x - sh.first_tile[k]) * kTileGroups + threadIdx.x * 2;
+    Vec<u64, 2> res[kCH];
+    masked_tile<S, uint8_t, kCommitBlock, kCH>(sh.match[k], sh.stride[k], mk.in_mask[k], mk.out_mask[k], mk.uniform_voters[k], base, res);
+#pragma unroll
+    for (int c = 0; c < kCH; ++c) store_stream<u64, 2>(commit + base + (u64)c * kCommitBlock * 2, res[c]);
+}
+
+template <int S, int MODE>
+__global__ __launch_bounds__(kCommitBlock) void k_commit_masked_many_report(const ManyReport sh, const ManyMasks mk) {
+    static_assert(MODE != kStore, "the plain pass is k_commit_masked_many");
+    u32 k = 0;
+    for (u32 i = 1; i < sh.n; ++i) k = blockIdx.x >= sh.first_tile[i] ? i : k;
+    const u32 tile = blockIdx.x - sh.first_tile[k];
+    const u64 base = (u64)tile * kTileGroups + threadIdx.x * 2;
+    Vec<u64, 2> res[kCH];
+    masked_tile<S, uint8_t, kCommitBlock, kCH>(sh.match[k], sh.stride[k], mk.in_mask[k], mk.out_mask[k], mk.uniform_voters[k], base, res);
+    finish_tile<kCH, kCommitBlock, MODE>(res, base, sh.groups[k], sh.commit[k], LogBounds{sh.term_start[k], sh.last_index[k]},
+                                         Report{sh.bits[k], sh.counts[k], sh.super[k], sh.super_next[k], sh.super_words[k]}, tile);
 }
 constexpr int kMidBlock = 256;                 // tile shape of K2 at 9..16 slots
 constexpr int kMidTileGroups = kMidBlock * 2;  // 512; divides kPlaneAlign

@@ -1781,21 +1781,52 @@ int rafthip_commit(rafthip_engine* e) {
     return launch_commit<kStore>(e, &bg);
 }
 
+}  // extern "C"
+
+namespace {
+// How one launch can serve a set of engines (the shards of one GPU):
+//   kManyUniform  every engine has the same uniform config of 1..8 voters: K1m
+//   kManyMasked   every engine has the same S <= 8 and takes the lane-per-group kernels; some carry per-group
+//                 masks (a conf change in flight), the others a uniform config: K2m
+//   kManySingle   anything else: engine by engine
+enum ManyKind { kManySingle = 0, kManyUniform, kManyMasked };
+ManyKind many_kind(rafthip_engine* const* engines, u32 n) {
+    const rafthip_engine* e0 = engines[0];
+    bool uni = e0->uniform_voters >= 1 && e0->uniform_voters <= 8, masked = e0->S <= 8;
+    for (u32 i = 0; i < n; ++i) {
+        const rafthip_engine* e = engines[i];
+        if (e->device != e0->device) return kManySingle;
+        if (!e->uniform || e->uniform_voters != e0->uniform_voters) uni = false;
+        if (e->S != e0->S) masked = false;
+        if (!e->uniform && !e->in_mask) masked = false;
+    }
+    return uni ? kManyUniform : masked ? kManyMasked : kManySingle;
+}
+void fill_many_masks(rafthip_engine* const* engines, u32 n, ManyMasks* mk) {
+    for (u32 k = 0; k < n; ++k) {
+        const rafthip_engine* e = engines[k];
+        mk->in_mask[k] = e->uniform ? nullptr : static_cast<const uint8_t*>(e->in_mask);
+        mk->out_mask[k] = e->uniform ? nullptr : static_cast<const uint8_t*>(e->out_mask);
+        mk->uniform_voters[k] = (uint8_t)(e->uniform ? e->uniform_voters : 0);
+    }
+}
+}  // namespace
+
+extern "C" {
+
 int rafthip_commit_many(rafthip_engine* const* engines, uint32_t n) {
     if (!engines || n == 0) return fail(RAFTHIP_EINVAL, "engines is NULL or n is 0");
     for (u32 i = 0; i < n; ++i)
         if (!engines[i]) return fail(RAFTHIP_EINVAL, "engines[%u] is NULL", i);
     rafthip_engine* e0 = engines[0];
-    // One launch needs: one GPU, the K1 shape (a uniform config of 1..8 voters, the same in every
-    // shard).  Anything else is the per-engine pass, engine by engine — same results.
-    bool one_launch = true, one_stream = true;
-    for (u32 i = 0; i < n; ++i) {
-        const rafthip_engine* e = engines[i];
-        if (e->device != e0->device || !e->uniform || e->uniform_voters != e0->uniform_voters) one_launch = false;
-        if (e->stream != e0->stream) one_stream = false;
-    }
-    if (e0->uniform_voters == 0 || e0->uniform_voters > 8) one_launch = false;
-    if (!one_launch) {
+    // One launch needs: one GPU and either the K1 shape (a uniform config of 1..8 voters, the same in every
+    // shard) or the K2 shape (the same S <= 8 in every shard, masks or not).  Anything else is the per-engine
+    // pass, engine by engine — same results.
+    const ManyKind kind = many_kind(engines, n);
+    bool one_stream = true;
+    for (u32 i = 0; i < n; ++i)
+        if (engines[i]->stream != e0->stream) one_stream = false;
+    if (kind == kManySingle) {
         for (u32 i = 0; i < n; ++i) {
             int rc = rafthip_commit(engines[i]);
             if (rc) return rc;
@@ -1842,14 +1873,28 @@ int rafthip_commit_many(rafthip_engine* const* engines, uint32_t n) {
             e->stats.groups_evaluated += e->G;
         }
         sh.first_tile[sh.n] = tiles;
-        switch (e0->uniform_voters) {
+        if (kind == kManyUniform) {
+            switch (e0->uniform_voters) {
 #define RAFTHIP_CASE_MANY(V)                                                                             \
     case V:                                                                                             \
         hipLaunchKernelGGL((k_commit_uniform_many<V>), dim3(tiles), dim3(kCommitBlock), 0, st, sh);      \
         break;
-            RAFTHIP_CASE_MANY(1) RAFTHIP_CASE_MANY(2) RAFTHIP_CASE_MANY(3) RAFTHIP_CASE_MANY(4)
-            RAFTHIP_CASE_MANY(5) RAFTHIP_CASE_MANY(6) RAFTHIP_CASE_MANY(7) RAFTHIP_CASE_MANY(8)
+                RAFTHIP_CASE_MANY(1) RAFTHIP_CASE_MANY(2) RAFTHIP_CASE_MANY(3) RAFTHIP_CASE_MANY(4)
+                RAFTHIP_CASE_MANY(5) RAFTHIP_CASE_MANY(6) RAFTHIP_CASE_MANY(7) RAFTHIP_CASE_MANY(8)
 #undef RAFTHIP_CASE_MANY
+            }
+        } else {
+            ManyMasks mk{};
+            fill_many_masks(engines + lo, sh.n, &mk);
+            switch (e0->S) {
+#define RAFTHIP_CASE_MANYM(SS)                                                                           \
+    case SS:                                                                                            \
+        hipLaunchKernelGGL((k_commit_masked_many<SS>), dim3(tiles), dim3(kCommitBlock), 0, st, sh, mk);  \
+        break;
+                RAFTHIP_CASE_MANYM(1) RAFTHIP_CASE_MANYM(2) RAFTHIP_CASE_MANYM(3) RAFTHIP_CASE_MANYM(4)
+                RAFTHIP_CASE_MANYM(5) RAFTHIP_CASE_MANYM(6) RAFTHIP_CASE_MANYM(7) RAFTHIP_CASE_MANYM(8)
+#undef RAFTHIP_CASE_MANYM
+            }
         }
         hipError_t err = hipGetLastError();
         if (err != hipSuccess) rc = fail(RAFTHIP_EIO, "k_commit_uniform_many: %s", hipGetErrorString(err));
@@ -1873,15 +1918,11 @@ template <int MODE>
 static int commit_report_many(rafthip_engine* const* engines, u32 n, rafthip_commit_pair* const* dst, const uint64_t* max_pairs,
                               uint64_t* n_out) {
     rafthip_engine* e0 = engines[0];
-    bool one_launch = n <= (u32)kManyMax;
-    for (u32 i = 0; i < n; ++i) {
-        const rafthip_engine* e = engines[i];
-        if (e->device != e0->device || !e->uniform || e->uniform_voters != e0->uniform_voters) one_launch = false;
+    for (u32 i = 0; i < n; ++i)
         for (u32 k = 0; k < i; ++k)
-            if (engines[k] == e) return fail(RAFTHIP_EINVAL, "engines[%u] and engines[%u] are the same engine", k, i);
-    }
-    if (e0->uniform_voters == 0 || e0->uniform_voters > 8) one_launch = false;
-    if (!one_launch) {
+            if (engines[k] == engines[i]) return fail(RAFTHIP_EINVAL, "engines[%u] and engines[%u] are the same engine", k, i);
+    const ManyKind kind = n <= (u32)kManyMax ? many_kind(engines, n) : kManySingle;
+    if (kind == kManySingle) {
         for (u32 i = 0; i < n; ++i) {
             int rc = commit_report<MODE>(engines[i], dst ? dst[i] : nullptr, max_pairs ? max_pairs[i] : 0, &n_out[i]);
             if (rc) return rc;
@@ -1962,14 +2003,28 @@ static int commit_report_many(rafthip_engine* const* engines, u32 n, rafthip_com
         e->stats.groups_evaluated += e->G;
     }
     sh.first_tile[n] = pk.first_tile[n] = tiles;
-    switch (e0->uniform_voters) {
+    if (kind == kManyUniform) {
+        switch (e0->uniform_voters) {
 #define RAFTHIP_CASE_MR(V)                                                                                     \
     case V:                                                                                                   \
         hipLaunchKernelGGL((k_commit_uniform_many_report<V, MODE>), dim3(tiles), dim3(kCommitBlock), 0, st, sh); \
         break;
-        RAFTHIP_CASE_MR(1) RAFTHIP_CASE_MR(2) RAFTHIP_CASE_MR(3) RAFTHIP_CASE_MR(4)
-        RAFTHIP_CASE_MR(5) RAFTHIP_CASE_MR(6) RAFTHIP_CASE_MR(7) RAFTHIP_CASE_MR(8)
+            RAFTHIP_CASE_MR(1) RAFTHIP_CASE_MR(2) RAFTHIP_CASE_MR(3) RAFTHIP_CASE_MR(4)
+            RAFTHIP_CASE_MR(5) RAFTHIP_CASE_MR(6) RAFTHIP_CASE_MR(7) RAFTHIP_CASE_MR(8)
 #undef RAFTHIP_CASE_MR
+        }
+    } else {
+        ManyMasks mk{};
+        fill_many_masks(engines, n, &mk);
+        switch (e0->S) {
+#define RAFTHIP_CASE_MRM(SS)                                                                                        \
+    case SS:                                                                                                       \
+        hipLaunchKernelGGL((k_commit_masked_many_report<SS, MODE>), dim3(tiles), dim3(kCommitBlock), 0, st, sh, mk); \
+        break;
+            RAFTHIP_CASE_MRM(1) RAFTHIP_CASE_MRM(2) RAFTHIP_CASE_MRM(3) RAFTHIP_CASE_MRM(4)
+            RAFTHIP_CASE_MRM(5) RAFTHIP_CASE_MRM(6) RAFTHIP_CASE_MRM(7) RAFTHIP_CASE_MRM(8)
+#undef RAFTHIP_CASE_MRM
+        }
     }
     hipLaunchKernelGGL(k_pack_changed_many, dim3(tiles), dim3(kBlock), 0, st, pk);
     hipError_t err = hipGetLastError();
@@ -3175,16 +3230,38 @@ int shot_run(int device, u64 G, u32 S, size_t cell, size_t res, const void* plan
     std::atomic<bool> abort{false};
     std::atomic<int> retire_error{(int)hipSuccess};
     for (auto& r : staged) r.store(0);
+    // Waiting between the roles: a few hundred pause instructions (a chunk is ~25 us of link time, most hand-offs
+    // arrive within that), then the thread sleeps on a condition variable until a counter moves — no runnable
+    // thread burns a host core while it has nothing to do (RAFTHIP_SHOT_SPIN=1 restores the yield() loops of
+    // round 2 for A/B runs, tools/oneshot_rate.py).  Every counter update is followed by signal().
+    std::mutex pmu;
+    std::condition_variable pcv;
+    const bool spin_only = getenv("RAFTHIP_SHOT_SPIN") != nullptr;
+    auto signal = [&] {
+        if (spin_only) return;
+        { std::lock_guard<std::mutex> l(pmu); }  // a waiter is either before its predicate check or already asleep
+        pcv.notify_all();
+    };
+    auto wait_until = [&](auto&& ready) {  // returns when ready() or abort
+        if (spin_only) {
+            while (!ready() && !abort.load()) std::this_thread::yield();
+            return;
+        }
+        for (int i = 0; i < 256; ++i) {
+            if (ready() || abort.load()) return;
+            _mm_pause();
+        }
+        std::unique_lock<std::mutex> l(pmu);
+        pcv.wait(l, [&] { return ready() || abort.load(); });
+    };
     const bool trace = getenv("RAFTHIP_SHOT_TRACE") != nullptr;
     double t_ready = 0, t_launch = 0, t_event = 0, t_out = 0;  // t_event / t_out: written by the one thread that retires
     auto tick = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_begin = tick();
     auto stage_chunk = [&](u64 k) {
         const int slot = (int)(k % kShotSlots);
-        while (retired.load(std::memory_order_acquire) + kShotSlots <= k) {
-            if (abort.load()) return;
-            std::this_thread::yield();
-        }
+        wait_until([&] { return retired.load(std::memory_order_acquire) + kShotSlots > k; });
+        if (abort.load()) return;
         const u64 g0 = start[k], cnt = start[k + 1] - g0;
         char* dst = c->in[slot];
         for (u32 s = 0; s < S; ++s)
@@ -3192,6 +3269,7 @@ int shot_run(int device, u64 G, u32 S, size_t cell, size_t res, const void* plan
         stage_copy(dst + planes_b, static_cast<const char*>(in_mask) + g0 * mb, cnt * mb);
         if (out_mask) stage_copy(dst + planes_b + mask_b, static_cast<const char*>(out_mask) + g0 * mb, cnt * mb);
         staged[slot].fetch_add(1, std::memory_order_release);
+        signal();
     };
     auto retire = [&](u64 k) -> hipError_t {
         const int slot = (int)(k % kShotSlots);
@@ -3202,6 +3280,7 @@ int shot_run(int device, u64 G, u32 S, size_t cell, size_t res, const void* plan
         const u64 g0 = start[k], cnt = start[k + 1] - g0;
         memcpy(static_cast<char*>(result) + g0 * res, c->out[slot], cnt * res);
         retired.store(k + 1, std::memory_order_release);
+        signal();
         t_event += t1 - t0;
         t_out += tick() - t1;
         return hipSuccess;
@@ -3230,14 +3309,13 @@ int shot_run(int device, u64 G, u32 S, size_t cell, size_t res, const void* plan
         if (role.fetch_add(1) == 0) {  // the retirer
             (void)hipSetDevice(device);
             for (u64 k = 0; k < nchunks; ++k) {
-                while (launched.load(std::memory_order_acquire) <= k) {
-                    if (abort.load()) return;
-                    std::this_thread::yield();
-                }
+                wait_until([&] { return launched.load(std::memory_order_acquire) > k; });
+                if (abort.load()) return;
                 const hipError_t err = retire(k);
                 if (err != hipSuccess) {
                     retire_error.store((int)err);
                     abort.store(true);
+                    signal();
                     return;
                 }
             }
@@ -3263,18 +3341,21 @@ int shot_run(int device, u64 G, u32 S, size_t cell, size_t res, const void* plan
         } else if (k == 0) {
             stage_chunk(0);
         }
-        while (!rc && staged[slot].load(std::memory_order_acquire) < k / kShotSlots + 1) {
-            if (abort.load()) break;
-            std::this_thread::yield();
-        }
+        if (!rc) wait_until([&] { return staged[slot].load(std::memory_order_acquire) >= k / kShotSlots + 1; });
         if (rc || abort.load()) break;
         const double t1 = tick();
         t_ready += t1 - t0;
         rc = launch_chunk(k);
-        if (!rc) launched.store(k + 1, std::memory_order_release);
+        if (!rc) {
+            launched.store(k + 1, std::memory_order_release);
+            signal();
+        }
         t_launch += tick() - t1;
     }
-    if (rc) abort.store(true);
+    if (rc) {
+        abort.store(true);
+        signal();
+    }
     if (nhelpers) {
         shot_helpers_wait(c);
         if (!rc && retire_error.load() != (int)hipSuccess)

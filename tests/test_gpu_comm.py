@@ -7,6 +7,7 @@ over gloo (tests/test_multigpu_cpu.py)."""
 import numpy as np
 import pytest
 
+import oracle
 import raft_amd
 from raft_amd import multigpu
 from raft_amd.capi import PAIR_DTYPE, Comm, PinnedArray, comm_unique_id
@@ -28,6 +29,7 @@ def _engine_pair(G, S, seed, uniform):
         else:
             e.upload_config(in_mask, out_mask)
         e.upload_match(match)
+    a.shadow = dict(match=match, cfg=dict(uniform_voters=uniform) if uniform else dict(in_mask=in_mask, out_mask=out_mask))
     return a, b, rng
 
 
@@ -48,6 +50,7 @@ def test_one_rank_allgather_equals_commit_changed(G, S, uniform):
         assert (comm.rank, comm.nranks) == (0, 1) and comm.max_pairs_per_rank >= G
         # exchanges with very different pair counts in a row: all groups, a few, none, many again —
         # the width guess is wrong in both directions
+        prev = np.zeros(G, dtype=np.uint64)
         for k, n_acks in enumerate([0, 500, 0, G // 2, 3]):
             recs = _acks(rng, G, S, n_acks, (k + 1) << 41)
             a.scatter_acks(recs)
@@ -58,6 +61,12 @@ def test_one_rank_allgather_equals_commit_changed(G, S, uniform):
             assert np.array_equal(got["group"], want["group"] + np.uint64(base))
             assert np.array_equal(got["commit"], want["commit"])
             assert np.array_equal(a.read_commit(), b.read_commit())
+            # and against the oracle's changed set, not only the twin engine
+            assert oracle.scatter_acks(a.shadow["match"], recs) == 0
+            after = oracle.batch_committed(a.shadow["match"], **a.shadow["cfg"])
+            ch = np.flatnonzero(after != prev)
+            prev = after
+            assert np.array_equal(got["group"], ch.astype(np.uint64) + np.uint64(base)) and np.array_equal(got["commit"], after[ch])
     finally:
         comm.close()
         a.close()
@@ -139,6 +148,8 @@ def test_one_rank_dense_allgather_is_the_commit_plane(G, S, uniform):
         planes, w = comm.commit_allgather_dense()
         assert w == width and planes.shape == (1, width)
         assert np.array_equal(planes[0, :G], want)
+        assert oracle.scatter_acks(a.shadow["match"], recs) == 0
+        assert np.array_equal(planes[0, :G], oracle.batch_committed(a.shadow["match"], **a.shadow["cfg"]))
         buf = torch.zeros(width, dtype=torch.int64, device="cuda:0")
         none, w = comm.commit_allgather_dense(dst=buf.data_ptr(), dst_elems=width)
         assert none is None and np.array_equal(buf[:G].cpu().numpy().view(np.uint64), want)

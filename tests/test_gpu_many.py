@@ -98,6 +98,20 @@ def test_commit_report_many_equals_the_single_engine_calls(advance):
         many.append(pair[0])
         twins.append(pair[1])
         mats.append(m)
+    # the oracle's view of every shard: what its commit plane holds, and the pairs a pass must report
+    held = [np.zeros(G, dtype=np.uint64) for G in sizes]
+
+    def oracle_pairs(i):
+        mci = oracle.batch_committed(mats[i], uniform_voters=V)
+        if advance:  # raftLog.maybeCommit on the [term_first, term_last] summary (log.go:447-456)
+            moved = (mci > held[i]) & (mci >= np.uint64(1 << 29)) & (mci <= np.uint64(1 << 40))
+            held[i] = np.where(moved, mci, held[i])
+        else:
+            moved = mci != held[i]
+            held[i] = mci
+        ch = np.flatnonzero(moved)
+        return ch.astype(np.uint64), held[i][ch]
+
     try:
         es = EngineSet(many)
         for step in range(4):
@@ -116,6 +130,11 @@ def test_commit_report_many_equals_the_single_engine_calls(advance):
                 assert counts[i] == n, (step, i)
                 assert np.array_equal(outs[i], want), (step, i)
                 assert np.array_equal(many[i].read_commit(), b.read_commit()), (step, i)
+                og, oc = oracle_pairs(i)  # and against the oracle, not only the twin
+                k = len(outs[i])
+                assert counts[i] == len(og) and k == (min(len(og), room[i]) if room else len(og)), (step, i)
+                assert np.array_equal(outs[i]["group"], og[:k]) and np.array_equal(outs[i]["commit"], oc[:k]), (step, i)
+                assert np.array_equal(many[i].read_commit(), held[i]), (step, i)
             if step == 2:
                 assert counts == [0] * len(sizes)
         # device destinations, count-only for one shard
@@ -131,10 +150,12 @@ def test_commit_report_many_equals_the_single_engine_calls(advance):
         assert none is None
         for i, b in enumerate(twins):
             want, n = (b.commit_advance if advance else b.commit_changed)()
-            assert counts[i] == n
+            og, oc = oracle_pairs(i)
+            assert counts[i] == n == len(og)
             if room[i]:
                 got = bufs[i][:2 * n].cpu().numpy().view(raft_amd.PAIR_DTYPE)
                 assert np.array_equal(got, want)
+                assert np.array_equal(got["group"], og) and np.array_equal(got["commit"], oc)
     finally:
         for e in many + twins:
             e.close()
@@ -163,3 +184,68 @@ def test_commit_report_many_mixed_configs_fall_back_and_duplicates_are_refused()
     finally:
         a.close()
         b.close()
+
+
+@pytest.mark.parametrize("S", [6, 3, 8])
+def test_commit_many_and_report_many_with_masked_shards(S):
+    """A host in the middle of a conf change: some shards carry per-group joint masks (quorum/joint.go:49-56),
+    others still the uniform config.  Same S <= 8 everywhere -> one K2m launch; results against the oracle, shard by
+    shard, for the plain pass, the changed report and the term-guarded report."""
+    rng = np.random.default_rng(600 + S)
+    sizes = [1, 2047, 2049, 90_000, 4097, 33_000]
+    hi = (1 << S) - 1
+    engines, mats, cfgs = [], [], []
+    for k, G in enumerate(sizes):
+        e = raft_amd.Engine(G, S, device=0)
+        m = rng.integers(1, 1 << 40, size=(S, G), dtype=np.uint64)
+        if k % 3 == 2:  # a shard that has not entered a joint config
+            v = min(S, 5)
+            e.set_uniform_config(v)
+            cfgs.append(dict(uniform_voters=v))
+        else:
+            m0 = rng.integers(1, hi, size=G, dtype=np.uint64, endpoint=True).astype(np.uint8)
+            m1 = np.where(rng.random(G) < (0.0 if k == 1 else 0.5), rng.integers(0, hi, size=G, dtype=np.uint64, endpoint=True), 0).astype(np.uint8)
+            e.upload_config(m0, m1)
+            cfgs.append(dict(in_mask=m0, out_mask=m1))
+        e.upload_match(m)
+        engines.append(e)
+        mats.append(m)
+    try:
+        es = EngineSet(engines)
+        es.commit()
+        held = []
+        for e, m, c in zip(engines, mats, cfgs):
+            want = oracle.batch_committed(m, **c)
+            assert np.array_equal(e.read_commit(), want)
+            held.append(want)
+        assert all(e.stats()["commit_launches"] == 1 for e in engines)
+        # changed report after new acks
+        for e, m in zip(engines, mats):
+            bump = rng.random(m.shape) < 0.1
+            m[bump] += np.uint64(1 << 41)
+            e.upload_match(m)
+        outs, counts = es.commit_report()
+        for i, (e, m, c) in enumerate(zip(engines, mats, cfgs)):
+            want = oracle.batch_committed(m, **c)
+            ch = np.flatnonzero(want != held[i])
+            assert counts[i] == len(ch), i
+            assert np.array_equal(outs[i]["group"], ch.astype(np.uint64)) and np.array_equal(outs[i]["commit"], want[ch]), i
+            assert np.array_equal(e.read_commit(), want)
+            held[i] = want
+        # the term-guarded report: only groups whose new index lies inside [term_first, term_last] move
+        for e, m in zip(engines, mats):
+            e.upload_term_range(np.full(e.G, 1 << 42, dtype=np.uint64), np.full(e.G, (1 << 42) + (1 << 41), dtype=np.uint64))
+            bump = rng.random(m.shape) < 0.3
+            m[bump] += np.uint64(1 << 42)
+            e.upload_match(m)
+        outs, counts = es.commit_report(advance=True)
+        for i, (e, m, c) in enumerate(zip(engines, mats, cfgs)):
+            mci = oracle.batch_committed(m, **c)
+            adv = (mci > held[i]) & (mci >= np.uint64(1 << 42)) & (mci <= np.uint64((1 << 42) + (1 << 41)))
+            ch = np.flatnonzero(adv)
+            assert counts[i] == len(ch), i
+            assert np.array_equal(outs[i]["group"], ch.astype(np.uint64)) and np.array_equal(outs[i]["commit"], mci[ch]), i
+            assert np.array_equal(e.read_commit(), np.where(adv, mci, held[i]))
+    finally:
+        for e in engines:
+            e.close()

@@ -1,11 +1,13 @@
 """rafthip_commit_changed_static — the allocation-free variant of
 rafthip_commit_changed (include/rafthip.h): same pairs, same commit plane, scratch
 in the library's static device array.  Through the C ABI (ctypes), bit-exact
-against rafthip_commit_changed on twin engines, two calls in a row on one GPU, the
+against rafthip_commit_changed on twin engines AND against the oracle's changed set
+(oracle.batch_committed before / after the acks), two calls in a row on one GPU, the
 second on a smaller input (the array keeps the first call's contents)."""
 import numpy as np
 import pytest
 
+import oracle
 import raft_amd
 from raft_amd.capi import PAIR_DTYPE, PinnedArray, RafthipError
 
@@ -27,6 +29,9 @@ def _twin(G, S, seed, joint):
         else:
             e.set_uniform_config(min(S, 5))
         e.upload_match(match)
+    # the oracle's shadow of engine a: planes, config, and what its commit plane holds
+    a.shadow = dict(match=match, prev=np.zeros(G, dtype=np.uint64),
+                    cfg=dict(in_mask=in_mask, out_mask=out_mask) if joint else dict(uniform_voters=min(S, 5)))
     return a, b, match, rng
 
 
@@ -48,6 +53,12 @@ def _round(a, b, recs, dst_kind):
     assert n == n_want
     assert np.array_equal(got["group"], want["group"]) and np.array_equal(got["commit"], want["commit"])
     assert np.array_equal(a.read_commit(), b.read_commit())
+    sh = a.shadow
+    assert oracle.scatter_acks(sh["match"], recs) == 0
+    after = oracle.batch_committed(sh["match"], **sh["cfg"])
+    ch = np.flatnonzero(after != sh["prev"])
+    sh["prev"] = after
+    assert n == len(ch) and np.array_equal(got["group"], ch.astype(np.uint64)) and np.array_equal(got["commit"], after[ch])
     return n
 
 

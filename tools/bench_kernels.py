@@ -126,6 +126,32 @@ def main():
         timed("k_commit_masked<6> no joint group (K2)", "group", G, 8 * 6 + 2 + 8, e.commit)
     del m
 
+    # ---- K2m: a host in the middle of a conf change — 12 shards of 2^20 groups, cfg3 mix, one launch ----------
+    if not args.only or args.only in "k_commit_masked_many<6> (K2m)":
+        from raft_amd.capi import EngineSet
+        Gs = (1 << 20) >> sh
+        shards = []
+        for k in range(12):  # 12 x 58 MiB: every pass reads cold HBM
+            mk = gu.dist_a(0x5EED0300 + k, 6, Gs)
+            a0, a1 = cfg3_masks(Gs, 0x5EED0300 + k)
+            e = raft_amd.Engine(Gs, 6, stream=stream.cuda_stream)
+            e.upload_config(a0, a1)
+            e.upload_match(mk)
+            shards.append(e)
+        es = EngineSet(shards)
+        timed("k_commit_masked_many<6> 12 shards of 2^20, cfg3 mix, one launch (K2m)", "group", 12 * Gs, 58, es.commit)
+
+        def one_by_one():
+            for e in shards:
+                e.commit()
+        timed("k_commit_masked<6> the same 12 shards, one launch each (K2)", "group", 12 * Gs, 58, one_by_one)
+        d_pairs = [torch.empty(2 * Gs, dtype=torch.int64, device=dev) for _ in shards]
+        timed("commit_report_many, 12 masked shards, nothing changes (K2m + k_pack_changed_many)", "group", 12 * Gs, 58 + 8,
+              lambda: es.commit_report(max_pairs=Gs, dsts=[d.data_ptr() for d in d_pairs]), iters=5)
+        for e in shards:
+            e.close()
+        del shards, d_pairs
+
     # ---- wide voters ------------------------------------------------------------------------
     for Sw in (9, 16, 32, 64):
         G = (1 << 22) >> sh
