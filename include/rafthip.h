@@ -78,6 +78,14 @@ typedef struct rafthip_engine rafthip_engine;
  * of the default one-group-per-lane register network.  Same results; kept
  * selectable for A/B measurement. */
 #define RAFTHIP_FLAG_WIDE_BITONIC 1u
+/* rafthip_scatter_acks has two forms with the same result: one 64-bit atomic max per
+ * ack, and — for batches of device-resident records that touch a fair share of the
+ * engine's cells — a partition of the acks by tile followed by one LDS-staged update
+ * of every tile.  By default the call picks by batch size;
+ * _SCATTER_ATOMIC pins the first form, _SCATTER_PARTITION the second whenever the
+ * engine's shape admits it (for A/B measurement and tests). */
+#define RAFTHIP_FLAG_SCATTER_ATOMIC 2u
+#define RAFTHIP_FLAG_SCATTER_PARTITION 4u
 
 typedef struct rafthip_config {
     uint32_t struct_size; /* sizeof(rafthip_config), for ABI growth */

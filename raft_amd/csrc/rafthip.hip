@@ -22,6 +22,7 @@
 
 #include "kernels.h"
 #include "progress.h"
+#include "scatter_part.h"
 #include "wire.h"
 #include "rafthip.h"
 #include "rafthip_internal.h"
@@ -169,6 +170,12 @@ struct rafthip_engine {
     // scatter
     Ack* ack_buf = nullptr;  // staging for host-resident ack / msg records (both 16 B)
     u64 ack_cap = 0;
+    int scatter_mode = 0;    // 0 auto, 1 always atomics (RAFTHIP_FLAG_SCATTER_ATOMIC), 2 partition whenever it can run
+    Ack* part_a = nullptr;   // K5p (scatter_part.h): records by bucket, then by tile
+    Ack* part_b = nullptr;
+    u64 part_cap = 0;
+    u32* part_words = nullptr;  // tile counts / bases / cursors, bucket cursors, chunk table, flag
+    bool part_attr = false;     // the kernels' LDS sizes have been raised on this device
     u64* d_rejected = nullptr;  // [0] acks without Progress, [1] msgs without Progress, [2] msgs of other types
     u64* h_scalar = nullptr;    // pinned, 4 x u64
     u64* d_scalar = nullptr;    // the same words as kernels address them (a total stored there needs no copy back)
@@ -703,7 +710,10 @@ int rafthip_create(const rafthip_config* cfg, rafthip_engine** out) {
                     (u64)cfg->num_groups);
     if (cfg->num_slots == 0 || cfg->num_slots > RAFTHIP_MAX_SLOTS)
         return fail(RAFTHIP_EINVAL, "num_slots %u outside [1, %u]", cfg->num_slots, RAFTHIP_MAX_SLOTS);
-    if (cfg->flags & ~RAFTHIP_FLAG_WIDE_BITONIC) return fail(RAFTHIP_EINVAL, "unknown flags 0x%x", cfg->flags);
+    if (cfg->flags & ~(RAFTHIP_FLAG_WIDE_BITONIC | RAFTHIP_FLAG_SCATTER_ATOMIC | RAFTHIP_FLAG_SCATTER_PARTITION))
+        return fail(RAFTHIP_EINVAL, "unknown flags 0x%x", cfg->flags);
+    if ((cfg->flags & RAFTHIP_FLAG_SCATTER_ATOMIC) && (cfg->flags & RAFTHIP_FLAG_SCATTER_PARTITION))
+        return fail(RAFTHIP_EINVAL, "RAFTHIP_FLAG_SCATTER_ATOMIC and RAFTHIP_FLAG_SCATTER_PARTITION exclude each other");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(RAFTHIP_ENODEV, "no HIP device available (this library has no CPU path)");
@@ -725,6 +735,7 @@ int rafthip_create(const rafthip_config* cfg, rafthip_engine** out) {
     e->stride = round_up(e->G, kPlaneAlign);
     e->mbytes = mask_bytes_for(e->S);
     e->wide_bitonic = (cfg->flags & RAFTHIP_FLAG_WIDE_BITONIC) != 0;
+    e->scatter_mode = (cfg->flags & RAFTHIP_FLAG_SCATTER_ATOMIC) ? 1 : (cfg->flags & RAFTHIP_FLAG_SCATTER_PARTITION) ? 2 : 0;
     int rc = RAFTHIP_OK;
     do {
         if (cfg->stream) {
@@ -771,7 +782,7 @@ int rafthip_destroy(rafthip_engine* e) {
                     e->ack_result, e->rep_bits, e->packed,      e->rep_counts, e->rep_super, e->ack_buf,
                     e->d_rejected, e->self_mask, e->term_first, e->term_last, e->hb_commit, e->in_term,
                     e->wire_hdr, e->d_wire_counts, e->pp.rec, e->pp.ring_index, e->pp.ring_bytes,
-                    e->first_index, e->vote_first};
+                    e->first_index, e->vote_first, e->part_a, e->part_b, e->part_words};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     for (void* b : e->stage_buf)
@@ -984,6 +995,90 @@ int rafthip_upload_commit(rafthip_engine* e, uint64_t first, uint64_t count, con
 
 // ---- compute -------------------------------------------------------------
 
+}  // extern "C"
+
+namespace {
+// Tile of K5p for this engine: the largest power of two of groups whose S rows fit 72 KB of LDS.
+u32 part_tile_shift(const rafthip_engine* e) {
+    u32 shift = 10;
+    while (((size_t)e->S << shift) * sizeof(u64) > 72u * 1024u) --shift;
+    return shift;
+}
+
+// Whether this batch of device-resident records takes the partitioned form (scatter_part.h).  It pays once the
+// batch touches a fair share of the cells: its cost is ~5 passes over the records plus one over all of Match,
+// K5's is one scattered atomic per record (the break-even is near one ack per six cells).
+bool part_wanted(const rafthip_engine* e, u64 n) {
+    if (e->scatter_mode == 1 || getenv("RAFTHIP_SCATTER_ATOMIC")) return false;
+    const u32 tiles = (u32)(e->stride >> part_tile_shift(e));
+    if (round_up(tiles, 1u << kPartLB) > kPartMaxTiles || n > kMaxRecordsPerLaunch) return false;
+    if (e->scatter_mode == 2) return true;
+    return n >= (1ull << 21) && n * 6 >= (u64)e->S * e->stride;
+}
+
+int scatter_partitioned(rafthip_engine* e, const Ack* d_recs, u64 n) {
+    const u32 shift = part_tile_shift(e);
+    const u32 tiles = (u32)(e->stride >> shift);
+    const u32 tiles_pad = (u32)round_up(tiles, 1u << kPartLB), nb = tiles_pad >> kPartLB;
+    int rc;
+    if (e->part_cap < n) {
+        if (e->part_a || e->part_b) {
+            HIP_TRY(hipStreamSynchronize(e->stream));
+            if (e->part_a) HIP_TRY(hipFree(e->part_a));
+            e->part_a = nullptr;
+            if (e->part_b) HIP_TRY(hipFree(e->part_b));
+            e->part_b = nullptr;
+            e->part_cap = 0;
+        }
+        if ((rc = ensure(e, e->part_a, (size_t)n * sizeof(Ack), false))) return rc;
+        if ((rc = ensure(e, e->part_b, (size_t)n * sizeof(Ack), false))) return rc;
+        e->part_cap = n;
+    }
+    // one block of words: counts (zero between calls), bases, cursors, bucket cursors, chunk table, flag
+    const size_t words = (size_t)kPartMaxTiles * 3 + 1 + kPartMaxBuckets * 2 + 1 + 1;
+    if ((rc = ensure(e, e->part_words, words * sizeof(u32), true))) return rc;
+    PartBufs pb;
+    pb.tile_count = e->part_words;
+    pb.tile_base = pb.tile_count + kPartMaxTiles;
+    pb.tile_cursor = pb.tile_base + kPartMaxTiles + 1;
+    pb.bucket_cursor = pb.tile_cursor + kPartMaxTiles;
+    pb.chunk_first = pb.bucket_cursor + kPartMaxBuckets;
+    pb.flag = pb.chunk_first + kPartMaxBuckets + 1;
+    const size_t lds_count = (size_t)tiles_pad * sizeof(u32), lds_stage = (size_t)kPartChunk * sizeof(Ack),
+                 lds_cells = ((size_t)e->S << shift) * sizeof(u64);
+    if (!e->part_attr) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_count), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)(kPartMaxTiles * sizeof(u32))));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_partition<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_stage));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_partition<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_stage));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_apply), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
+        e->part_attr = true;
+    }
+    hipStream_t st = e->stream;
+    const u32 count_wgs = 512;
+    const u64 slice = (n + count_wgs - 1) / count_wgs;
+    hipLaunchKernelGGL(k_part_count, dim3(count_wgs), dim3(kPartCountBlock), lds_count, st, d_recs, n, slice, e->G, e->S, shift, tiles_pad,
+                       pb.tile_count, e->d_rejected);
+    hipLaunchKernelGGL(k_part_scan, dim3(1), dim3(1024), 0, st, pb, tiles_pad, nb);
+    const u64 chunks1 = (n + kPartChunk - 1) / kPartChunk, chunks2 = chunks1 + nb;  // pass 2: an upper bound, the table has the count
+    const u32 persistent = 512;  // two workgroups per CU (64 KB of LDS each)
+    hipLaunchKernelGGL(k_part_partition<1>, dim3((u32)(chunks1 < persistent ? chunks1 : persistent)), dim3(kPartBlock), lds_stage, st,
+                       d_recs, n, e->G, e->S, shift, nb, pb, e->part_a);
+    hipLaunchKernelGGL(k_part_partition<2>, dim3((u32)(chunks2 < persistent ? chunks2 : persistent)), dim3(kPartBlock), lds_stage, st,
+                       static_cast<const Ack*>(e->part_a), n, e->G, e->S, shift, nb, pb, e->part_b);
+    hipLaunchKernelGGL(k_part_apply, dim3(tiles), dim3(kPartBlock), lds_cells, st, e->match, e->stride, e->S, shift,
+                       static_cast<const Ack*>(e->part_b), pb);
+    // a batch the scan found too skewed for tiles: K5's atomics on the original records (decided on the device)
+    const u64 flagged_wgs = (n + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(k_scatter_acks_flagged, dim3((u32)(flagged_wgs < kPartFlaggedGrid ? flagged_wgs : kPartFlaggedGrid)), dim3(kBlock), 0, st, e->match, e->stride, e->G, e->S,
+                       d_recs, n, static_cast<const u32*>(pb.flag));
+    HIP_TRY(hipGetLastError());
+    return RAFTHIP_OK;
+}
+}  // namespace
+
+extern "C" {
+
 int rafthip_scatter_acks(rafthip_engine* e, const rafthip_ack* recs, uint64_t n) {
     if (!e) return fail(RAFTHIP_EINVAL, "engine is NULL");
     if (n == 0) return RAFTHIP_OK;
@@ -993,6 +1088,14 @@ int rafthip_scatter_acks(rafthip_engine* e, const rafthip_ack* recs, uint64_t n)
     bool staged = false;
     int rc = stage_records(e, recs, n, &d_recs, &staged);
     if (rc) return rc;
+    // device-resident records (the caller's, or the engine's staged copy of pageable memory — not page-locked memory,
+    // which the kernels read over the link: one pass over it is all the link allows)
+    if (is_device_ptr(d_recs) && part_wanted(e, n)) {
+        if ((rc = scatter_partitioned(e, static_cast<const Ack*>(d_recs), n))) return rc;
+        if (staged) HIP_TRY(hipStreamSynchronize(e->stream));
+        e->stats.acks_applied += n;
+        return RAFTHIP_OK;
+    }
     for (u64 off = 0; off < n; off += kMaxRecordsPerLaunch) {  // a launch stays below 2^32 lanes
         const u64 m = n - off < kMaxRecordsPerLaunch ? n - off : kMaxRecordsPerLaunch;
         const u32 blocks = (u32)((m + kBlock - 1) / kBlock);
