@@ -50,7 +50,9 @@ HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: 8.0 TB/s spec
 ATOMIC_RATE_PEAK = 26.6e9         # scattered 8-byte atomics/s, measured (tools/scatter_probe.py)
 CFG3_GROUPS = 1 << 24             # BASELINE configs[2]: 16M groups, joint, across the GPUs
 CFG5_GROUPS = 1 << 24             # BASELINE configs[4]: 7 voters + 2 learners, 4 acks per group
-EXCHANGE_TIMEOUT_S = 120          # the exchange extra may not hold the headline line back longer than this
+EXCHANGE_TIMEOUT_S = int(os.environ.get("RAFTHIP_BENCH_EXCHANGE_TIMEOUT", "120"))  # the exchange extra may not hold the line back longer
+LAUNCH_TIMEOUT_S = int(os.environ.get("RAFTHIP_BENCH_LAUNCH_TIMEOUT", "1500"))      # launch_ranks: longest wait for rank 0
+EXIT_EXCHANGE_FAILED = 3          # the JSON line was written, but the one collective hung or failed: the record must not read rc 0
 CPU_EXTRA = {}
 
 
@@ -77,9 +79,14 @@ def launch_ranks(n, argv):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rcs = [procs[0].returncode]
-    deadline = time.time() + 120
+    try:
+        out, _ = procs[0].communicate(timeout=LAUNCH_TIMEOUT_S)
+        rcs = [procs[0].returncode]
+    except subprocess.TimeoutExpired:
+        procs[0].kill()  # exactly the children this function started, nothing by pattern
+        out, _ = procs[0].communicate()
+        rcs = [124]
+    deadline = time.time() + (120 if rcs[0] != 124 else 1)
     for p in procs[1:]:
         try:
             rcs.append(p.wait(timeout=max(1.0, deadline - time.time())))
@@ -89,6 +96,31 @@ def launch_ranks(n, argv):
     sys.stdout.write(out.decode("utf-8", "replace"))
     sys.stdout.flush()
     return max((abs(rc) for rc in rcs), default=0)
+
+
+# ---------------------------------------------------------------------------------------------
+# the exchange extra must never hide a stuck or failed collective behind exit code 0
+# ---------------------------------------------------------------------------------------------
+
+def guarded_exchange(fn, extra, timeout_s):
+    """Run fn() on a helper thread.  True when it has not returned after timeout_s (a collective that
+    never completes): the caller still prints its line, then leaves with exit_code()."""
+    import threading
+    th = threading.Thread(target=fn, daemon=True)
+    th.start()
+    th.join(timeout_s)
+    if th.is_alive():
+        extra["commit_changed_allgather_error"] = "no return within %d s" % timeout_s
+        return True
+    return False
+
+
+def exit_code(extra, world, hung):
+    """What the process ends with AFTER the JSON line: a hung exchange, or — with more than one rank, where
+    the exchange is the thing a scaling run exists to exercise — a failed one, is not success."""
+    if hung or (world > 1 and extra.get("commit_changed_allgather_error")):
+        return EXIT_EXCHANGE_FAILED
+    return 0
 
 
 # ---------------------------------------------------------------------------------------------
@@ -337,7 +369,28 @@ def run_cfg5(raft_amd, torch, dev, local_rank, stream, rank, world, reps):
         t_sc /= reps
         t_co /= reps
         sec = t_sc + t_co
+        # which form rafthip_scatter_acks took (its own rule, rafthip.hip part_wanted): the partitioned one (K5p) for
+        # device-resident batches of >= 2^21 records that touch at least a sixth of the cells, while the engine has
+        # at most 32768 tiles of 1024 groups; and the other form on a twin engine pinned to atomics, for the A/B
+        stride = (G + 4095) // 4096 * 4096
+        partitioned = n_acks >= (1 << 21) and 6 * n_acks >= S * stride and stride // 1024 <= 32768
+        t_at = None
+        try:
+            from raft_amd.capi import FLAG_SCATTER_ATOMIC
+            with raft_amd.Engine(G, S, device=local_rank, stream=stream.cuda_stream, flags=FLAG_SCATTER_ATOMIC) as ea:
+                ea.set_uniform_config(V)
+                ea.upload_match(torch.full((S, G), base, dtype=torch.int64, device=dev))
+                t_at = 0.0
+                for _ in range(min(reps, 2) + 1):
+                    with torch.cuda.stream(stream):
+                        one_pass()
+                    torch.cuda.synchronize()
+                    t_at = _timed(stream, lambda: ea.scatter_acks(recs.data_ptr(), n_acks), 1)  # the last one counts (first: warm-up)
+        except Exception:
+            t_at = None
         return {"groups_total": CFG5_GROUPS, "groups_this_rank": G, "acks_this_rank": n_acks, "slots": S, "voters": V,
+                "scatter_form": "partitioned (K5p: count, scan, 2 partition passes, tile apply in LDS)" if partitioned else "atomic (K5)",
+                "scatter_atomic_form_ms": None if t_at is None else round(t_at * 1e3, 4),
                 "scatter_ms": round(t_sc * 1e3, 4), "commit_ms": round(t_co * 1e3, 4),
                 "groups_per_s_this_rank": G / sec, "acks_per_s_this_rank": n_acks / t_sc,
                 "scatter_frac_of_hbm_peak": round(n_acks * 24 / t_sc / 1e9 / HBM_PEAK_GBS, 4),
@@ -455,7 +508,7 @@ def main():
                    "config": {"workload": ("cfg3: 2^24 groups x 6 slots, joint mix, ProgressTracker.Committed, sharded by group range"
                                            if args.config == "cfg3" else
                                            "cfg5: 2^24 groups x (7 voters + 2 learners), 2^26 MsgAppResp acks per step routed by "
-                                           "group range -> atomicMax scatter -> commit pass; step time by HIP events"),
+                                           "group range -> rafthip_scatter_acks (partitioned form at this size) -> commit pass; step time by HIP events"),
                               "groups_total": total, "sharding": "group-id range, no data-path collective"},
                    "extra": {"rank0": info}}
             if args.config == "cfg3":
@@ -463,9 +516,14 @@ def main():
                 out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": ach / HBM_PEAK_GBS, "traffic": None, "kernel": info["kernel"]}
             else:
-                out["roofline"] = {"bound": "atomic-rate", "achieved": info["acks_per_s_this_rank"], "peak": ATOMIC_RATE_PEAK,
-                                   "unit": "atomics/s", "frac": info["scatter_frac_of_atomic_rate"], "traffic": None,
-                                   "kernel": "k_scatter_acks", "frac_of_hbm_peak": info["scatter_frac_of_hbm_peak"]}
+                # both ceilings: the HBM line at the algorithmic 24 B per ack (16 B record + 8 B cell), and the rate of
+                # scattered 8-byte atomics the one-atomic-per-ack form is bound by
+                ach = info["acks_per_s_this_rank"] * 24 / 1e9
+                out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                                   "kernel": "rafthip_scatter_acks: " + info["scatter_form"],
+                                   "atomic_rate_ceiling": {"achieved": info["acks_per_s_this_rank"], "peak": ATOMIC_RATE_PEAK,
+                                                           "unit": "acks/s", "frac": info["scatter_frac_of_atomic_rate"]}}
             emit(out)
         e.close()
         if world > 1:
@@ -635,10 +693,13 @@ def main():
                 recs["slot"] = rng.integers(0, VOTERS, size=len(recs))
                 if rehearse:
                     exch = lambda: multigpu.commit_changed_allgather(e0, rank * G_BATCH, cdev)  # noqa: E731
-                    ranks_seen = world
+                    extra["gloo_ranks_seen"] = world  # a rehearsal: no RCCL communicator exists
                 else:
                     comm = multigpu.make_comm(e0, group_base=rank * G_BATCH)
-                    ranks_seen = comm.nranks
+                    # comm.nranks is RCCL's own ncclCommCount (rafthip_comm_info): did RCCL see all N ranks?
+                    extra["rccl_ranks_seen"] = int(comm.nranks)
+                    if comm.nranks != world:
+                        raise RuntimeError("the communicator has %d ranks, the job %d" % (comm.nranks, world))
                     gathered = torch.empty(2 * comm.nranks * comm.max_pairs_per_rank, dtype=torch.int64, device=dev)
 
                     def exch():
@@ -656,7 +717,6 @@ def main():
                 if not rehearse:
                     allp = allp.cpu().numpy().view(raft_amd.PAIR_DTYPE)
             (t_ex,) = max_over_ranks(min(times[1:]))
-            extra["rccl_ranks_seen"] = int(ranks_seen)
             extra["changed_pairs_rank0"] = int(n_changed)
             extra["commit_changed_allgather_ms"] = round(1e3 * t_ex, 3)
             extra["commit_changed_allgather_first_ms"] = round(1e3 * times[0], 3)
@@ -668,12 +728,7 @@ def main():
         except Exception as ex:
             extra["commit_changed_allgather_error"] = "%s: %s" % (type(ex).__name__, str(ex)[:300])
 
-    th = threading.Thread(target=exchange, daemon=True)
-    th.start()
-    th.join(EXCHANGE_TIMEOUT_S)
-    if th.is_alive():
-        exchange_hung[0] = True
-        extra["commit_changed_allgather_error"] = "no return within %d s" % EXCHANGE_TIMEOUT_S
+    exchange_hung[0] = guarded_exchange(exchange, extra, EXCHANGE_TIMEOUT_S)
 
     if not args.no_extras and world == 1 and not exchange_hung[0]:
         # HIP-graph-amortised launch (SURVEY.md §8d caveat): one rotation over all batches, one shard per
@@ -816,11 +871,14 @@ def main():
             out["extra"].update(CPU_EXTRA)
         emit(out)
 
+    code = exit_code(extra, world, exchange_hung[0])
     if exchange_hung[0]:
-        os._exit(0)  # a collective is stuck on the helper thread: no teardown can complete
+        os._exit(code)  # a collective is stuck on the helper thread: no teardown can complete; the line is out
     if world > 1:
-        dist.barrier()
+        dist.barrier()  # the job's own process group is healthy (the failure, if any, was inside the exchange)
         dist.destroy_process_group()
+    if code:
+        sys.exit(code)
 
 
 if __name__ == "__main__":

@@ -653,6 +653,7 @@ int rafthip_comm_create(rafthip_engine *e, const rafthip_comm_id *id, int rank, 
 int rafthip_comm_create_all(rafthip_engine **engines, int n, const uint64_t *group_base, uint64_t max_pairs_per_rank,
                             rafthip_comm **out);
 int rafthip_comm_destroy(rafthip_comm *c);
+/* *nranks is RCCL's own count of the communicator's ranks (ncclCommCount). */
 int rafthip_comm_info(const rafthip_comm *c, int *rank, int *nranks, uint64_t *max_pairs_per_rank);
 
 /* rafthip_commit_changed (advance == 0) or rafthip_commit_advance (advance != 0)

@@ -2930,6 +2930,13 @@ int rafthip_comm_create(rafthip_engine* e, const rafthip_comm_id* id, int rank, 
             rc = fail(RAFTHIP_EIO, "ncclCommInitRank: %s", ncclGetErrorString(r));
             break;
         }
+        int cnt = 0;
+        r = ncclCommCount(c->nccl, &cnt);
+        if (r != ncclSuccess || cnt != nranks) {
+            rc = fail(RAFTHIP_EIO, "ncclCommCount: the communicator has %d ranks, %d were asked for (%s)", cnt, nranks,
+                      r == ncclSuccess ? "ok" : ncclGetErrorString(r));
+            break;
+        }
         if ((rc = comm_agree_and_alloc(c, max_pairs_per_rank))) break;
         // the capacity every rank uses = the largest one asked for, the dense width = the largest plane
         // stride: an in-place all-gather of both + max
@@ -3076,7 +3083,14 @@ int rafthip_comm_destroy(rafthip_comm* c) {
 int rafthip_comm_info(const rafthip_comm* c, int* rank, int* nranks, uint64_t* max_pairs_per_rank) {
     if (!c) return fail(RAFTHIP_EINVAL, "comm is NULL");
     if (rank) *rank = c->rank;
-    if (nranks) *nranks = c->nranks;
+    if (nranks) {
+        *nranks = c->nranks;
+        if (c->nccl) {  // RCCL's own count: what a scaling run reports as "ranks the communicator really has"
+            int cnt = 0;
+            NCCL_TRY(ncclCommCount(c->nccl, &cnt));
+            *nranks = cnt;
+        }
+    }
     if (max_pairs_per_rank) *max_pairs_per_rank = c->cap;
     return RAFTHIP_OK;
 }

@@ -153,6 +153,58 @@ def test_cfg5_scatter_then_commit_7_voters_2_learners(oracle):
         assert n == 0
 
 
+def test_cfg5_at_the_config_size_16m_groups_64m_acks(oracle):
+    """BASELINE cfg5 as SURVEY.md 8(d) sizes it on one GPU: 2^24 groups x (7 voters + 2 learners), M = 4 G = 2^26
+    acks (about 5 % stale, duplicate cells) -> rafthip_scatter_acks -> commit pass; whole Match planes, whole commit
+    plane and every changed pair against the oracle.  This is the size at which the planes (1.2 GB) leave the TLB
+    reach and at which the default engine takes the partitioned scatter (K5p); the records are device-resident, as
+    a host that decodes on the GPU or receives over GPU-direct holds them.  A second engine pinned to the atomic
+    form must leave the same planes."""
+    import torch
+    from raft_amd.capi import FLAG_SCATTER_ATOMIC
+    G, S, V = 1 << 24, 9, 7
+    match = gu.dist_b(0x5EED0005, S, G) & np.uint64((1 << 63) - 1)
+    rng = np.random.default_rng(0x5EED0055)
+    M = 4 * G
+    recs = np.zeros(M, dtype=raft_amd.ACK_DTYPE)
+    recs["group"] = rng.integers(0, G, size=M, dtype=np.uint32)
+    recs["slot"] = rng.integers(0, S, size=M, dtype=np.uint32)
+    old = match[recs["slot"], recs["group"]]
+    recs["index"] = old + rng.integers(0, 64, size=M, dtype=np.uint64)
+    stale = rng.random(M) < 0.05
+    recs["index"][stale] = old[stale] >> np.uint64(1)
+    del old, stale
+    before = oracle.batch_committed(match, uniform_voters=V, threads=0)
+    match0 = match.copy()
+    d_recs = torch.from_numpy(recs.view(np.uint8)).to("cuda:0")
+    with raft_amd.Engine(G, S) as e:
+        e.set_uniform_config(V)
+        e.upload_match(match)
+        e.upload_commit(before)
+        e.scatter_acks(d_recs.data_ptr(), M)
+        pairs, n = e.commit_changed()
+        assert oracle.scatter_acks(match, recs) == 0  # match is now the oracle's planes after the acks
+        got = e.read_match()
+        assert np.array_equal(got, match)
+        del got
+        after = oracle.batch_committed(match, uniform_voters=V, threads=0)
+        assert np.array_equal(e.read_commit(), after)
+        ch = np.flatnonzero(after != before)
+        assert n == len(ch) and n > G // 4
+        assert np.array_equal(pairs["group"], ch.astype(np.uint64)) and np.array_equal(pairs["commit"], after[ch])
+        assert (after >= before).all()
+        assert e.stats()["acks_rejected"] == 0
+    del pairs, ch, before
+    with raft_amd.Engine(G, S, flags=FLAG_SCATTER_ATOMIC) as a:  # the other form of the same call
+        a.set_uniform_config(V)
+        a.upload_match(match0)
+        del match0
+        a.scatter_acks(d_recs.data_ptr(), M)
+        a.commit()
+        assert np.array_equal(a.read_commit(), after)
+        assert np.array_equal(a.read_match(), match)
+
+
 def test_cfg5_heartbeats_to_the_wire(oracle):
     """cfg5 shape (2^22 groups x 7 voters + 2 learners): the 3.4e7 serialized MsgHeartbeat of one bcastHeartbeat,
     whole output byte for byte against the oracle, plus what holds at any size: the Commit each message carries

@@ -2,6 +2,8 @@
 all-gather (runs on CPU; the per-rank compute is covered by the GPU tests)."""
 import os
 import socket
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -9,6 +11,8 @@ import torch.multiprocessing as mp
 
 from raft_amd import multigpu
 from raft_amd.capi import ACK_DTYPE, PAIR_DTYPE
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_shard_ranges_cover_everything():
@@ -165,3 +169,42 @@ def test_bench_refuses_a_rank_environment_that_disagrees_with_gpus():
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        env=env, capture_output=True, text=True, timeout=120)
     assert p.returncode != 0 and "WORLD_SIZE=3 but --gpus 2" in p.stderr and p.stdout == ""
+
+
+_HUNG_EXCHANGE = r"""
+import json, os, sys, time
+sys.path.insert(0, %r)
+import bench
+from raft_amd import multigpu
+
+multigpu.make_comm = lambda *a, **k: time.sleep(3600)   # a communicator whose rendezvous never completes
+extra = {}
+
+def exchange():   # the shape of bench.py's exchange extra: everything behind make_comm never happens
+    comm = multigpu.make_comm(None, group_base=0)
+    extra["rccl_ranks_seen"] = comm.nranks
+
+hung = bench.guarded_exchange(exchange, extra, 1)
+sys.stdout.write(json.dumps({"metric": "m", "value": 1.0, "extra": extra}) + "\n")
+sys.stdout.flush()
+code = bench.exit_code(extra, int(sys.argv[1]), hung)
+os._exit(code) if hung else sys.exit(code)
+"""
+
+
+def test_bench_reports_a_hung_exchange_with_the_line_and_a_nonzero_exit():
+    """A stuck collective is the finding a scaling run exists to surface: the JSON line is still printed (the headline
+    was measured before the exchange extra), but the process must not end with rc 0."""
+    import json
+    p = subprocess.run([sys.executable, "-c", _HUNG_EXCHANGE % ROOT, "8"], capture_output=True, text=True, timeout=60)
+    assert p.returncode == 3, (p.returncode, p.stderr[-500:])
+    line = json.loads(p.stdout.strip().splitlines()[-1])
+    assert "no return within" in line["extra"]["commit_changed_allgather_error"] and "rccl_ranks_seen" not in line["extra"]
+
+
+def test_bench_exit_code_rules():
+    import bench
+    assert bench.exit_code({}, 1, False) == 0 and bench.exit_code({}, 8, False) == 0
+    assert bench.exit_code({"commit_changed_allgather_error": "x"}, 1, False) == 0   # one rank: an extra, reported in the line
+    assert bench.exit_code({"commit_changed_allgather_error": "x"}, 2, False) == 3   # N > 1: the exchange is what is being exercised
+    assert bench.exit_code({}, 1, True) == 3
