@@ -1049,6 +1049,8 @@ int scatter_partitioned(rafthip_engine* e, const Ack* d_recs, u64 n) {
     if (!e->part_attr) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_count), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)(kPartMaxTiles * sizeof(u32))));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_scan), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)(kPartMaxTiles * sizeof(u32))));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_partition<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_stage));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_partition<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_stage));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_apply), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
@@ -1059,7 +1061,7 @@ int scatter_partitioned(rafthip_engine* e, const Ack* d_recs, u64 n) {
     const u64 slice = (n + count_wgs - 1) / count_wgs;
     hipLaunchKernelGGL(k_part_count, dim3(count_wgs), dim3(kPartCountBlock), lds_count, st, d_recs, n, slice, e->G, e->S, shift, tiles_pad,
                        pb.tile_count, e->d_rejected);
-    hipLaunchKernelGGL(k_part_scan, dim3(1), dim3(1024), 0, st, pb, tiles_pad, nb);
+    hipLaunchKernelGGL(k_part_scan, dim3(1), dim3(1024), lds_count, st, pb, tiles_pad, nb);
     const u64 chunks1 = (n + kPartChunk - 1) / kPartChunk, chunks2 = chunks1 + nb;  // pass 2: an upper bound, the table has the count
     const u32 persistent = 512;  // two workgroups per CU (64 KB of LDS each)
     hipLaunchKernelGGL(k_part_partition<1>, dim3((u32)(chunks1 < persistent ? chunks1 : persistent)), dim3(kPartBlock), lds_stage, st,

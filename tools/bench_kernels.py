@@ -227,14 +227,35 @@ def main():
     msgs["flags"] = 1
     d_recs = torch.from_numpy(recs.view(np.uint8)).to(dev)
     d_msgs = torch.from_numpy(msgs.view(np.uint8)).to(dev)
-    with raft_amd.Engine(G, Sv, stream=stream.cuda_stream) as e:
+    with raft_amd.Engine(G, Sv, stream=stream.cuda_stream, flags=raft_amd.capi.FLAG_SCATTER_ATOMIC) as e:
         e.set_uniform_config(7)
         e.upload_match(m)
-        timed("k_scatter_acks, random cells (K5)", "ack", N, 24, lambda: e.scatter_acks(d_recs.data_ptr(), N),
+        timed("k_scatter_acks, random cells (K5, atomic form pinned)", "ack", N, 24, lambda: e.scatter_acks(d_recs.data_ptr(), N),
               atomics_per_unit=1)
         timed("k_ingest_msgs, random cells (K7)", "msg", N, 24 + 4, lambda: e.ingest_msgs(d_msgs.data_ptr(), N),
               atomics_per_unit=1)
         timed("k_commit_uniform<7> over 9 slots (K1)", "group", G, 64, e.commit)
+    with raft_amd.Engine(G, Sv, stream=stream.cuda_stream) as e:  # the default: this batch takes the partitioned form
+        e.set_uniform_config(7)
+        e.upload_match(m)
+        timed("rafthip_scatter_acks, partitioned form, random cells (K5p: count + scan + 2 partition passes + apply)", "ack", N, 24,
+              lambda: e.scatter_acks(d_recs.data_ptr(), N), atomics_per_unit=1)
+    # the same at BASELINE cfg5's own size: 2^24 groups, 2^26 acks (1.2 GB of planes: past the TLB reach of scattered atomics)
+    if not sh and (not args.only or args.only in "K5 cfg5 full size"):
+        Gf, Nf = 1 << 24, 1 << 26
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(55)
+        big = torch.empty((Nf, 2), dtype=torch.int64, device=dev)
+        big[:, 0] = torch.randint(0, Gf, (Nf,), dtype=torch.int64, device=dev, generator=gen) | (
+            torch.randint(0, Sv, (Nf,), dtype=torch.int64, device=dev, generator=gen) << 32)
+        big[:, 1] = torch.randint(0, 1 << 62, (Nf,), dtype=torch.int64, device=dev, generator=gen)
+        for flags, tag in ((raft_amd.capi.FLAG_SCATTER_ATOMIC, "k_scatter_acks (K5, atomic form pinned)"),
+                           (0, "rafthip_scatter_acks, partitioned form (K5p)")):
+            with raft_amd.Engine(Gf, Sv, stream=stream.cuda_stream, flags=flags) as e:
+                e.set_uniform_config(7)
+                timed("%s, cfg5 full size: 2^26 acks over 2^24 groups x 9" % tag, "ack", Nf, 24,
+                      lambda: e.scatter_acks(big.data_ptr(), Nf), atomics_per_unit=1, iters=5)
+        del big
     # serialized responses (K8): same cells as the K7 stream, as gogo-protobuf bytes
     if not args.only or args.only in "k_ingest_wire, random cells (K8)":
         import wire_util as wu
@@ -366,10 +387,10 @@ def main():
     # sorted-by-group stream (a host that buckets acks by range)
     order = np.argsort(recs["group"], kind="stable")
     d_recs = torch.from_numpy(np.ascontiguousarray(recs[order]).view(np.uint8)).to(dev)
-    with raft_amd.Engine(G, Sv, stream=stream.cuda_stream) as e:
+    with raft_amd.Engine(G, Sv, stream=stream.cuda_stream, flags=raft_amd.capi.FLAG_SCATTER_ATOMIC) as e:
         e.set_uniform_config(7)
         e.upload_match(m)
-        timed("k_scatter_acks, group-sorted stream (K5)", "ack", N, 24, lambda: e.scatter_acks(d_recs.data_ptr(), N),
+        timed("k_scatter_acks, group-sorted stream (K5, atomic form pinned)", "ack", N, 24, lambda: e.scatter_acks(d_recs.data_ptr(), N),
               atomics_per_unit=1)
 
     print("\n| kernel | units/launch | B/unit | avg µs | GB/s | of 8 TB/s | units/s | of the scattered-atomic rate (26.6e9/s) |")

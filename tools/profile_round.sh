@@ -3,7 +3,7 @@
 # bench.py and for tools/bench_kernels.py.  Usage: tools/profile_round.sh <tag>
 # Writes everything under gpurun_out/<tag>_*; copy what you keep into profiles/.
 set -e -o pipefail
-tag=${1:-r02_a}
+tag=${1:-r03_a}
 out=gpurun_out
 mkdir -p $out
 export TMPDIR=/tmp

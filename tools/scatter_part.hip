@@ -91,6 +91,7 @@ int main(int argc, char** argv) {
     CK(hipMemset(m_b, 0, (size_t)S * G * 8));
     const size_t lds_count = (size_t)tiles_pad * 4, lds_stage = (size_t)kPartChunk * 16, lds_cells = ((size_t)S << shift) * 8;
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_count), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kPartMaxTiles * 4)));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_scan), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kPartMaxTiles * 4)));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_partition<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_stage));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_partition<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_stage));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_apply), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
@@ -112,7 +113,7 @@ int main(int argc, char** argv) {
         CK(hipEventRecord(ev[1], st));
         hipLaunchKernelGGL(k_part_count, dim3(nwg), dim3(kPartCountBlock), lds_count, st, d, N, slice, G, S, shift, tiles_pad, pb.tile_count, rej);
         CK(hipEventRecord(ev[2], st));
-        hipLaunchKernelGGL(k_part_scan, dim3(1), dim3(1024), 0, st, pb, tiles_pad, nb);
+        hipLaunchKernelGGL(k_part_scan, dim3(1), dim3(1024), lds_count, st, pb, tiles_pad, nb);
         CK(hipEventRecord(ev[3], st));
         hipLaunchKernelGGL(k_part_partition<1>, dim3((u32)(chunks1 < persistent ? chunks1 : persistent)), dim3(kPartBlock), lds_stage, st, d, N, G, S, shift, nb, pb, b1);
         CK(hipEventRecord(ev[4], st));
