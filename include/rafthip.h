@@ -86,6 +86,15 @@ typedef struct rafthip_engine rafthip_engine;
  * engine's shape admits it (for A/B measurement and tests). */
 #define RAFTHIP_FLAG_SCATTER_ATOMIC 2u
 #define RAFTHIP_FLAG_SCATTER_PARTITION 4u
+/* The Progress stepper (rafthip_step_progress, rafthip_step_wire) has two forms with the
+ * same result: K9 links the events of every Progress through a list head in its record
+ * (one scattered exchange per event) and steps them wherever they lie; K9p first brings
+ * the events into tile order with the partition passes of K5p and then links and steps
+ * them tile by tile, list heads in LDS.  By default the call picks by batch
+ * size; _STEP_LINKED pins the first form, _STEP_PARTITION the second whenever the engine's
+ * shape admits it (for A/B measurement and tests). */
+#define RAFTHIP_FLAG_STEP_LINKED 8u
+#define RAFTHIP_FLAG_STEP_PARTITION 16u
 
 typedef struct rafthip_config {
     uint32_t struct_size; /* sizeof(rafthip_config), for ABI growth */

@@ -21,6 +21,7 @@ MSG_APP_RESP, MSG_HEARTBEAT_RESP, MSG_APPENDED, MSGF_READ_CTX = 4, 9, 0xF0, 1
 PLANE_HEARTBEAT = 3
 FLAG_WIDE_BITONIC = 1
 FLAG_SCATTER_ATOMIC, FLAG_SCATTER_PARTITION = 2, 4
+FLAG_STEP_LINKED, FLAG_STEP_PARTITION = 8, 16
 
 PLANE_MATCH, PLANE_COMMIT, PLANE_VOTES = 0, 1, 2
 VOTE_PENDING, VOTE_LOST, VOTE_WON = 1, 2, 3

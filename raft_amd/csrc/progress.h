@@ -253,9 +253,11 @@ __device__ __forceinline__ MsgFields load_msg(const Msg* msgs, u64 i) {
 __global__ __launch_bounds__(kBlock) void k_progress_link(const Msg* __restrict__ msgs, u32 n, u64 G, u32 S,
                                                           u64 stride, ProgRec* __restrict__ rec,
                                                           u32* __restrict__ prev, u64* __restrict__ term_last,
-                                                          uint8_t* __restrict__ actions) {
+                                                          uint8_t* __restrict__ actions,
+                                                          const u32* __restrict__ only_if /* NULL, or a device flag: run only when set (K9p's fallback) */) {
     const u32 i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
+    if (only_if && !only_if[0]) return;
     const MsgFields f = load_msg(msgs, i);
     uint8_t act;
     if (f.type == kMsgAppended) {
@@ -280,9 +282,11 @@ __global__ __launch_bounds__(kBlock) void k_progress_apply(const Msg* __restrict
                                                            void* __restrict__ active, void* __restrict__ acks,
                                                            int mbytes, const u64* __restrict__ term_last,
                                                            const u64* __restrict__ first_index,
-                                                           uint8_t* __restrict__ actions) {
+                                                           uint8_t* __restrict__ actions,
+                                                           const u32* __restrict__ only_if /* as in k_progress_link */) {
     const u32 i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
+    if (only_if && !only_if[0]) return;
     const MsgFields own = load_msg(msgs, i);
     if (!prog_event_type(own.type) || (u64)own.group >= G || own.slot >= S) return;
     const u64 cell = (u64)own.slot * pl.stride + own.group;

@@ -23,6 +23,7 @@
 #include "kernels.h"
 #include "progress.h"
 #include "scatter_part.h"
+#include "progress_part.h"
 #include "wire.h"
 #include "rafthip.h"
 #include "rafthip_internal.h"
@@ -171,6 +172,8 @@ struct rafthip_engine {
     Ack* ack_buf = nullptr;  // staging for host-resident ack / msg records (both 16 B)
     u64 ack_cap = 0;
     int scatter_mode = 0;    // 0 auto, 1 always atomics (RAFTHIP_FLAG_SCATTER_ATOMIC), 2 partition whenever it can run
+    int step_mode = 0;       // the Progress stepper: 0 auto, 1 always K9's global lists (RAFTHIP_FLAG_STEP_LINKED), 2 K9p whenever it can run
+    bool prog_part_attr = false;  // K9p's kernels have had their LDS sizes raised on this device
     Ack* part_a = nullptr;   // K5p (scatter_part.h): records by bucket, then by tile
     Ack* part_b = nullptr;
     u64 part_cap = 0;
@@ -710,10 +713,13 @@ int rafthip_create(const rafthip_config* cfg, rafthip_engine** out) {
                     (u64)cfg->num_groups);
     if (cfg->num_slots == 0 || cfg->num_slots > RAFTHIP_MAX_SLOTS)
         return fail(RAFTHIP_EINVAL, "num_slots %u outside [1, %u]", cfg->num_slots, RAFTHIP_MAX_SLOTS);
-    if (cfg->flags & ~(RAFTHIP_FLAG_WIDE_BITONIC | RAFTHIP_FLAG_SCATTER_ATOMIC | RAFTHIP_FLAG_SCATTER_PARTITION))
+    if (cfg->flags & ~(RAFTHIP_FLAG_WIDE_BITONIC | RAFTHIP_FLAG_SCATTER_ATOMIC | RAFTHIP_FLAG_SCATTER_PARTITION |
+                       RAFTHIP_FLAG_STEP_LINKED | RAFTHIP_FLAG_STEP_PARTITION))
         return fail(RAFTHIP_EINVAL, "unknown flags 0x%x", cfg->flags);
     if ((cfg->flags & RAFTHIP_FLAG_SCATTER_ATOMIC) && (cfg->flags & RAFTHIP_FLAG_SCATTER_PARTITION))
         return fail(RAFTHIP_EINVAL, "RAFTHIP_FLAG_SCATTER_ATOMIC and RAFTHIP_FLAG_SCATTER_PARTITION exclude each other");
+    if ((cfg->flags & RAFTHIP_FLAG_STEP_LINKED) && (cfg->flags & RAFTHIP_FLAG_STEP_PARTITION))
+        return fail(RAFTHIP_EINVAL, "RAFTHIP_FLAG_STEP_LINKED and RAFTHIP_FLAG_STEP_PARTITION exclude each other");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(RAFTHIP_ENODEV, "no HIP device available (this library has no CPU path)");
@@ -736,6 +742,7 @@ int rafthip_create(const rafthip_config* cfg, rafthip_engine** out) {
     e->mbytes = mask_bytes_for(e->S);
     e->wide_bitonic = (cfg->flags & RAFTHIP_FLAG_WIDE_BITONIC) != 0;
     e->scatter_mode = (cfg->flags & RAFTHIP_FLAG_SCATTER_ATOMIC) ? 1 : (cfg->flags & RAFTHIP_FLAG_SCATTER_PARTITION) ? 2 : 0;
+    e->step_mode = (cfg->flags & RAFTHIP_FLAG_STEP_LINKED) ? 1 : (cfg->flags & RAFTHIP_FLAG_STEP_PARTITION) ? 2 : 0;
     int rc = RAFTHIP_OK;
     do {
         if (cfg->stream) {
@@ -1016,10 +1023,9 @@ bool part_wanted(const rafthip_engine* e, u64 n) {
     return n >= (1ull << 21) && n * 6 >= (u64)e->S * e->stride;
 }
 
-int scatter_partitioned(rafthip_engine* e, const Ack* d_recs, u64 n) {
-    const u32 shift = part_tile_shift(e);
-    const u32 tiles = (u32)(e->stride >> shift);
-    const u32 tiles_pad = (u32)round_up(tiles, 1u << kPartLB), nb = tiles_pad >> kPartLB;
+// The scratch the partition passes of K5p and K9p share (one engine, one stream: never at the same time): two
+// record buffers of n 16-byte records and one block of words.
+int part_scratch(rafthip_engine* e, u64 n, PartBufs* out) {
     int rc;
     if (e->part_cap < n) {
         if (e->part_a || e->part_b) {
@@ -1044,6 +1050,17 @@ int scatter_partitioned(rafthip_engine* e, const Ack* d_recs, u64 n) {
     pb.bucket_cursor = pb.tile_cursor + kPartMaxTiles;
     pb.chunk_first = pb.bucket_cursor + kPartMaxBuckets;
     pb.flag = pb.chunk_first + kPartMaxBuckets + 1;
+    *out = pb;
+    return RAFTHIP_OK;
+}
+
+int scatter_partitioned(rafthip_engine* e, const Ack* d_recs, u64 n) {
+    const u32 shift = part_tile_shift(e);
+    const u32 tiles = (u32)(e->stride >> shift);
+    const u32 tiles_pad = (u32)round_up(tiles, 1u << kPartLB), nb = tiles_pad >> kPartLB;
+    int rc;
+    PartBufs pb;
+    if ((rc = part_scratch(e, n, &pb))) return rc;
     const size_t lds_count = (size_t)tiles_pad * sizeof(u32), lds_stage = (size_t)kPartChunk * sizeof(Ack),
                  lds_cells = ((size_t)e->S << shift) * sizeof(u64);
     if (!e->part_attr) {
@@ -1339,7 +1356,8 @@ int rafthip_upload_campaign(rafthip_engine* e, uint64_t first, uint64_t count, c
 }
 
 static int progress_passes(rafthip_engine* e, const Msg* d_msgs, const u64* d_aux, uint64_t n, uint8_t* d_act,
-                           bool linked);
+                           bool linked, bool part);
+static bool prog_part_wanted(const rafthip_engine* e, u64 n);
 // Before a link pass: if an earlier call failed between its link and apply passes, zero every list head.
 static int clear_stale_heads(rafthip_engine* e) {
     if (!e->heads_dirty || !e->pp.rec) return RAFTHIP_OK;
@@ -1424,7 +1442,8 @@ static int wire_run(rafthip_engine* e, const uint8_t* bytes, const uint64_t* off
         d_prev = static_cast<u32*>(e->stage_buf[kStagePrev]);
     }
     HIP_TRY(hipMemsetAsync(e->d_wire_counts, 0, RAFTHIP_WIRE_STATUSES * sizeof(u64), e->stream));
-    if (to_progress) {
+    const bool part = to_progress && prog_part_wanted(e, n);  // K9p: the decode kernel leaves the linking to the tiles
+    if (to_progress && !part) {
         if ((rc = clear_stale_heads(e))) return rc;
         e->heads_dirty = true;  // the decode kernel links; cleared once the apply pass is on the stream
     }
@@ -1436,10 +1455,10 @@ static int wire_run(rafthip_engine* e, const uint8_t* bytes, const uint64_t* off
                            static_cast<const u32*>(d_groups) + off, m, e->G, e->S, static_cast<const u64*>(e->wire_hdr),
                            wire_hdr_words(e->S), e->match, e->stride, e->active, e->acks, e->mbytes,
                            d_msgs ? d_msgs + off : nullptr, d_status ? d_status + off : nullptr, e->d_wire_counts,
-                           d_aux ? d_aux + off : nullptr, e->pp.rec, d_prev, d_act, (u32)off);
+                           d_aux ? d_aux + off : nullptr, part ? nullptr : e->pp.rec, d_prev, d_act, (u32)off);
         HIP_TRY(hipGetLastError());
     }
-    if (to_progress && (rc = progress_passes(e, d_msgs, d_aux, n, d_act, true))) return rc;
+    if (to_progress && (rc = progress_passes(e, d_msgs, d_aux, n, d_act, !part, part))) return rc;
     if (e->campaigning) {
         // RecordVote for the vote responses the decode let through (status VOTE; every other vote
         // response left the kernel without a slot), first vote per peer in stream order
@@ -1681,28 +1700,105 @@ int rafthip_upload_first_index(rafthip_engine* e, uint64_t first, uint64_t count
     return RAFTHIP_OK;
 }
 
-// The link and apply passes over n device-resident records (d_act: device, n bytes).
+// Tile of K9p for this engine: the largest power of two of groups (at most 1024) whose S cell counters fit 64 KB of LDS.
+static u32 prog_part_tile_shift(const rafthip_engine* e) {
+    u32 shift = 10;
+    while (((size_t)e->S << shift) * sizeof(u32) > 64u * 1024u) --shift;
+    return shift;
+}
+
+// Whether a batch of n events takes the partitioned stepper (progress_part.h).  Its four passes in front of the apply
+// pass cost less per event than K9's link pass alone, so size only has to cover their fixed cost.
+static bool prog_part_wanted(const rafthip_engine* e, u64 n) {
+    if (e->step_mode == 1 || getenv("RAFTHIP_STEP_LINKED")) return false;
+    const u32 tiles = (u32)(e->stride >> prog_part_tile_shift(e));
+    if (round_up(tiles, 1u << kPartLB) > kPartMaxTiles || n > kMaxRecordsPerLaunch) return false;
+    if (e->step_mode == 2) return true;
+    return n >= (1ull << 18);
+}
+
+// K9p: count, scan, two partition passes, per-tile apply; K9's link and apply kernels behind the device-side
+// skew flag.  The caller has reserved kStagePrev for n words.
+static int progress_partitioned(rafthip_engine* e, const Msg* d_msgs, const u64* d_aux, u64 n, uint8_t* d_act, u32* prev) {
+    const u32 shift = prog_part_tile_shift(e);
+    const u32 tiles = (u32)(e->stride >> shift);
+    const u32 tiles_pad = (u32)round_up(tiles, 1u << kPartLB), nb = tiles_pad >> kPartLB;
+    int rc;
+    PartBufs pb;
+    if ((rc = part_scratch(e, n, &pb))) return rc;
+    const size_t lds_count = (size_t)tiles_pad * sizeof(u32), lds_stage2 = (size_t)kPartChunk * sizeof(Ack),
+                 lds_stage1 = lds_stage2 + kPartChunk, lds_cells = ((size_t)e->S << shift) * sizeof(u32);
+    if (!e->prog_part_attr) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_prog_part_count), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)(kPartMaxTiles * sizeof(u32))));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_scan), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)(kPartMaxTiles * sizeof(u32))));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_partition<1, kPartEvents>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_stage1));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_partition<2, kPartEvents>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_stage2));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_prog_part_apply), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    64 * 1024));
+        e->prog_part_attr = true;
+    }
+    if ((rc = clear_stale_heads(e))) return rc;  // the fallback links through the records' head words
+    hipStream_t st = e->stream;
+    const u32 count_wgs = 512;
+    const u64 slice = (n + count_wgs - 1) / count_wgs;
+    hipLaunchKernelGGL(k_prog_part_count, dim3(count_wgs), dim3(kPartCountBlock), lds_count, st, d_msgs, n, slice, e->G, e->S, shift,
+                       tiles_pad, pb.tile_count, e->term_last, d_act);
+    hipLaunchKernelGGL(k_part_scan, dim3(1), dim3(1024), lds_count, st, pb, tiles_pad, nb);
+    const u64 chunks1 = (n + kPartChunk - 1) / kPartChunk, chunks2 = chunks1 + nb;
+    const u32 persistent = 512;
+    hipLaunchKernelGGL((k_part_partition<1, kPartEvents>), dim3((u32)(chunks1 < persistent ? chunks1 : persistent)), dim3(kPartBlock),
+                       lds_stage1, st, reinterpret_cast<const Ack*>(d_msgs), n, e->G, e->S, shift, nb, pb, e->part_a);
+    hipLaunchKernelGGL((k_part_partition<2, kPartEvents>), dim3((u32)(chunks2 < persistent ? chunks2 : persistent)), dim3(kPartBlock),
+                       lds_stage2, st, static_cast<const Ack*>(e->part_a), n, e->G, e->S, shift, nb, pb, e->part_b);
+    e->pp.match = e->match;
+    hipLaunchKernelGGL(k_prog_part_apply, dim3(tiles), dim3(kProgPartBlock), lds_cells, st, static_cast<const Ack*>(e->part_b), e->part_a,
+                       d_aux, e->S, shift, e->pp, pb, e->active, e->acks, e->mbytes, static_cast<const u64*>(e->term_last),
+                       static_cast<const u64*>(e->first_index), d_act);
+    HIP_TRY(hipGetLastError());
+    // a batch the scan found piled onto one tile: K9's two passes over the original records (decided on the device;
+    // the usual case is two grids that leave at once)
+    const u32 blocks = (u32)((n + kBlock - 1) / kBlock);
+    e->heads_dirty = true;
+    hipLaunchKernelGGL(k_progress_link, dim3(blocks), dim3(kBlock), 0, st, d_msgs, (u32)n, e->G, e->S, e->stride, e->pp.rec, prev,
+                       e->term_last, d_act, static_cast<const u32*>(pb.flag));
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_progress_apply, dim3(blocks), dim3(kBlock), 0, st, d_msgs, d_aux, (u32)n, e->G, e->S, e->pp,
+                       static_cast<const u32*>(prev), e->active, e->acks, e->mbytes, static_cast<const u64*>(e->term_last),
+                       static_cast<const u64*>(e->first_index), d_act, static_cast<const u32*>(pb.flag));
+    HIP_TRY(hipGetLastError());
+    e->heads_dirty = false;
+    return RAFTHIP_OK;
+}
+
+// The Progress stepper over n device-resident records (d_act: device, n bytes).  `linked`: the decode kernel has
+// already linked the events into K9's lists; `part`: take K9p (never together with `linked`).
 static int progress_passes(rafthip_engine* e, const Msg* d_msgs, const u64* d_aux, uint64_t n, uint8_t* d_act,
-                           bool linked) {
+                           bool linked, bool part) {
     int rc;
     const size_t mb = (size_t)e->stride * e->mbytes;
     if ((rc = ensure(e, e->active, mb))) return rc;
     if ((rc = ensure(e, e->acks, mb))) return rc;
     if ((rc = stage_reserve(e, kStagePrev, (size_t)n * sizeof(u32)))) return rc;
     u32* prev = static_cast<u32*>(e->stage_buf[kStagePrev]);
+    if (part && !linked) return progress_partitioned(e, d_msgs, d_aux, n, d_act, prev);
     const u32 blocks = (u32)((n + kBlock - 1) / kBlock);
+    const u32* const always = nullptr;
     if (!linked) {
         int rc2 = clear_stale_heads(e);
         if (rc2) return rc2;
         e->heads_dirty = true;  // until the apply pass is on the stream
         hipLaunchKernelGGL(k_progress_link, dim3(blocks), dim3(kBlock), 0, e->stream, d_msgs, (u32)n, e->G, e->S,
-                           e->stride, e->pp.rec, prev, e->term_last, d_act);
+                           e->stride, e->pp.rec, prev, e->term_last, d_act, always);
         HIP_TRY(hipGetLastError());
     }
     e->pp.match = e->match;
     hipLaunchKernelGGL(k_progress_apply, dim3(blocks), dim3(kBlock), 0, e->stream, d_msgs, d_aux, (u32)n, e->G, e->S,
                        e->pp, static_cast<const u32*>(prev), e->active, e->acks, e->mbytes,
-                       static_cast<const u64*>(e->term_last), static_cast<const u64*>(e->first_index), d_act);
+                       static_cast<const u64*>(e->term_last), static_cast<const u64*>(e->first_index), d_act, always);
     HIP_TRY(hipGetLastError());
     e->heads_dirty = false;
     return RAFTHIP_OK;
@@ -1865,7 +1961,8 @@ int rafthip_step_progress(rafthip_engine* e, const rafthip_msg* msgs, const uint
         if ((rc = stage_reserve(e, kStageActions, (size_t)n))) return rc;
         d_act = static_cast<uint8_t*>(e->stage_buf[kStageActions]);
     }
-    if ((rc = progress_passes(e, static_cast<const Msg*>(d_recs), static_cast<const u64*>(d_aux), n, d_act, false)))
+    if ((rc = progress_passes(e, static_cast<const Msg*>(d_recs), static_cast<const u64*>(d_aux), n, d_act, false,
+                              is_device_ptr(d_recs) && prog_part_wanted(e, n))))
         return rc;
     bool wait = staged || (aux && d_aux != aux) || e->zero_copy_pending;
     e->zero_copy_pending = false;

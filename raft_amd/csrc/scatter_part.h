@@ -154,15 +154,40 @@ __global__ __launch_bounds__(1024) void k_part_scan(PartBufs pb, u32 tiles_pad, 
     if (t == 0) pb.flag[0] = s_max > kPartSkewLimit ? 1u : 0u;
 }
 
+// What a partition pass moves.  kPartAcks: 16-byte ack records (group, slot, index), unchanged from pass to pass.
+// kPartEvents (K9p, progress_part.h): pass 1 reads the 16-byte event records of rafthip_step_progress and writes
+// them PACKED — the bucket is known from a record's position after pass 1, so the key keeps only the group
+// within its bucket and has room for the stream index, which orders the events of one Progress:
+//   bits 0..16  group & (2^(tile_shift + 7) - 1)     bits 17..22 slot      bits 23..25 event code
+//   bit  26     reject     bits 27..28 flags & 3      bits 32..63 stream index;  second word: index
+enum { kPartAcks = 0, kPartEvents = 1 };
+constexpr u32 kEvKeySlotShift = 17, kEvKeyCodeShift = 23, kEvKeyRejectShift = 26, kEvKeyFlagsShift = 27;
+// event code of a record type the Progress stepper takes (progress.h: prog_event_type), 7 = not an event
+__device__ __forceinline__ u32 part_event_code(u32 type) {
+    switch (type) {
+        case 4: return 0;      // MsgAppResp
+        case 9: return 1;      // MsgHeartbeatResp
+        case 10: return 2;     // MsgUnreachable
+        case 11: return 3;     // MsgSnapStatus
+        case 0xF1: return 4;   // sent an append
+        case 0xF2: return 5;   // sent a snapshot
+        case 0xFE: return 6;   // a response only the host can step
+        default: return 7;
+    }
+}
+
 // One partition pass over chunks of kPartChunk records; persistent workgroups, the next chunk's
 // records are requested before the current one is staged.
 //   LEVEL 1: chunk c = records [c * chunk, +chunk) of src; digit = tile >> kPartLB; cursors = bucket_cursor
 //   LEVEL 2: chunk c lies inside one bucket (chunk table); digit = tile & 127; cursors = tile_cursor + bucket * 128
-template <int LEVEL>
+template <int LEVEL, int KIND = kPartAcks>
 __global__ __launch_bounds__(kPartBlock) void k_part_partition(const Ack* __restrict__ src, u64 n, u64 G, u32 S, u32 tile_shift, u32 nb,
                                                                PartBufs pb, Ack* __restrict__ dst) {
-    extern __shared__ ulonglong2 part_stage[];  // [kPartChunk]
+    extern __shared__ ulonglong2 part_stage[];  // [kPartChunk] (+ kPartChunk digit bytes for pass 1 over events)
     __shared__ u32 hist[kPartMaxBuckets], lstart[kPartMaxBuckets + 1], gbase[kPartMaxBuckets], wsum[4];
+    constexpr bool kPack = KIND == kPartEvents && LEVEL == 1;   // raw event records in, packed ones out
+    constexpr bool kPacked = KIND == kPartEvents && LEVEL == 2;  // packed in, packed out: every record is valid
+    uint8_t* const stage_dig = reinterpret_cast<uint8_t*>(part_stage + kPartChunk);  // kPack only
     if (pb.flag[0]) return;
     const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const u32 nchunks = LEVEL == 1 ? (u32)((n + kPartChunk - 1) / kPartChunk) : pb.chunk_first[nb];
@@ -213,6 +238,7 @@ __global__ __launch_bounds__(kPartBlock) void k_part_partition(const Ack* __rest
 #pragma unroll
         for (int j = 0; j < kPartR; ++j) rec[j] = nxt[j];
         const u32 my_cur0 = cur0;
+        const u64 my_lo = lo;
         const u32 cn = c + gridDim.x;
         const bool more = cn < nchunks;
         if (more) {
@@ -222,12 +248,30 @@ __global__ __launch_bounds__(kPartBlock) void k_part_partition(const Ack* __rest
         u32 rank[kPartR], dig[kPartR];
 #pragma unroll
         for (int j = 0; j < kPartR; ++j) {
-            const u32 group = (u32)rec[j].x, slot = (u32)(rec[j].x >> 32);
             dig[j] = 0xFFFFFFFFu;
-            if ((u64)group < G && slot < S) {
-                const u32 tile = group >> tile_shift;
-                dig[j] = LEVEL == 1 ? tile >> kPartLB : tile & ((1u << kPartLB) - 1u);
-                rank[j] = atomicAdd(&hist[dig[j]], 1u);
+            if constexpr (kPack) {
+                const u64 w = rec[j].x;
+                const u32 group = (u32)w, slot = (u32)(w >> 32) & 0xFFu, code = part_event_code((u32)(w >> 40) & 0xFFu);
+                if ((u64)group < G && slot < S && code < 7u) {  // an unfetched record reads as group 2^32-1
+                    dig[j] = (group >> tile_shift) >> kPartLB;
+                    const u64 stream = my_lo + (u64)j * kPartBlock + tid;
+                    rec[j].x = (u64)(group & ((1u << (tile_shift + kPartLB)) - 1u)) | ((u64)slot << kEvKeySlotShift) |
+                               ((u64)code << kEvKeyCodeShift) | ((u64)(((w >> 48) & 0xFFu) != 0) << kEvKeyRejectShift) |
+                               (((w >> 56) & 3u) << kEvKeyFlagsShift) | (stream << 32);
+                    rank[j] = atomicAdd(&hist[dig[j]], 1u);
+                }
+            } else if constexpr (kPacked) {
+                if (rec[j].x != ~0ull) {  // the filler of an unfetched record; a packed key never has bits 29..31 set
+                    dig[j] = ((u32)rec[j].x >> tile_shift) & ((1u << kPartLB) - 1u);
+                    rank[j] = atomicAdd(&hist[dig[j]], 1u);
+                }
+            } else {
+                const u32 group = (u32)rec[j].x, slot = (u32)(rec[j].x >> 32);
+                if ((u64)group < G && slot < S) {
+                    const u32 tile = group >> tile_shift;
+                    dig[j] = LEVEL == 1 ? tile >> kPartLB : tile & ((1u << kPartLB) - 1u);
+                    rank[j] = atomicAdd(&hist[dig[j]], 1u);
+                }
             }
         }
         __syncthreads();  // A: ranks complete
@@ -249,13 +293,22 @@ __global__ __launch_bounds__(kPartBlock) void k_part_partition(const Ack* __rest
         __syncthreads();  // C
 #pragma unroll
         for (int j = 0; j < kPartR; ++j)
-            if (dig[j] != 0xFFFFFFFFu) part_stage[lstart[dig[j]] + rank[j]] = rec[j];
+            if (dig[j] != 0xFFFFFFFFu) {
+                const u32 at = lstart[dig[j]] + rank[j];
+                part_stage[at] = rec[j];
+                if constexpr (kPack) stage_dig[at] = (uint8_t)dig[j];  // the packed key no longer names its bucket
+            }
         __syncthreads();  // D
         const u32 total = lstart[kPartMaxBuckets];
         for (u32 i = tid; i < total; i += kPartBlock) {
             const ulonglong2 r = part_stage[i];
-            const u32 tile = (u32)r.x >> tile_shift;
-            const u32 d = LEVEL == 1 ? tile >> kPartLB : tile & ((1u << kPartLB) - 1u);
+            u32 d;
+            if constexpr (kPack) {
+                d = stage_dig[i];
+            } else {
+                const u32 tile = (u32)r.x >> tile_shift;
+                d = LEVEL == 1 ? tile >> kPartLB : tile & ((1u << kPartLB) - 1u);
+            }
             *reinterpret_cast<ulonglong2*>(dst + (u64)gbase[d] + (i - lstart[d])) = r;
         }
         if (!more) break;

@@ -174,7 +174,36 @@ __device__ bool wire_parse(const R& rd, i64 pos, i64 end, WireFields& f) {
 // response type the group's campaign counts (0 = not campaigning).
 constexpr u32 kHdrTerm = 0, kHdrCtx = 1, kHdrCtxLen = 2, kHdrIds = 3;
 constexpr u32 kHdrCampaignShift = 8;
-__host__ __device__ __forceinline__ u32 wire_hdr_words(u32 S) { return (kHdrIds + S + 3u) & ~3u; }
+// Rows are whole 128-byte lines: a message's lookup is a random gather, bound by the number of lines it touches,
+// and up to 13 slots a row is exactly one (96-byte rows at 32-byte alignment straddled two 128-byte lines half
+// of the time).
+__host__ __device__ __forceinline__ u32 wire_hdr_words(u32 S) { return (kHdrIds + S + 15u) & ~15u; }
+constexpr u32 kHdrLineIds = 16 - kHdrIds;  // ids in the first line of a row
+
+// The first line of a group's row, all of it requested at once (eight 16-byte loads in flight instead of a
+// chain of dependent 8-byte ones), and the slot search over it.
+struct HdrLine {
+    u64 w[16];
+    __device__ __forceinline__ void load(const u64* row) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const Vec<u64, 2> v = load_vec<u64, 2>(row + 2 * k);
+            w[2 * k] = v.v[0];
+            w[2 * k + 1] = v.v[1];
+        }
+    }
+    // the first slot whose id is `from` (r.trk.Progress[m.From]); ids beyond the first line are read from the row
+    __device__ __forceinline__ u32 find(const u64* row, u32 S, u64 from) const {
+        u32 slot = kWireNoSlot;
+#pragma unroll
+        for (int s = (int)kHdrLineIds - 1; s >= 0; --s)
+            if ((u32)s < S && w[kHdrIds + s] == from) slot = (u32)s;
+        if (slot == kWireNoSlot)
+            for (u32 s = kHdrLineIds; s < S; ++s)
+                if (row[kHdrIds + s] == from) return s;
+        return slot;
+    }
+};
 
 __global__ __launch_bounds__(kWireBlock) void k_ingest_wire(
     const uint8_t* __restrict__ bytes, u64 nbytes, const u64* __restrict__ offsets,
@@ -247,8 +276,12 @@ __global__ __launch_bounds__(kWireBlock) void k_ingest_wire(
             } else if (f.nested) {
                 status = kWireNested;
             } else {
-                const u64* row = hdr + (u64)group * H;  // one or two lines hold all the group's lookup state
-                const u64 term = row[kHdrTerm];
+                // requesting the line before the parse, so that its latency runs under the byte loop, was measured:
+                // slower (1172 -> 1239 us per 2^24 messages; the kernel is bound by what it moves, not by latency)
+                const u64* row = hdr + (u64)group * H;  // one line holds all the group's lookup state (S <= 13)
+                HdrLine line;
+                line.load(row);
+                const u64 term = line.w[kHdrTerm];
                 // raft.go:1068-1076: a granted MsgPreVoteResp carries the pre-candidate's future term and does
                 // not make it a follower
                 if (f.term != 0 && f.term > term && !(f.type == kMsgPreVoteResp && !f.reject)) {
@@ -258,31 +291,17 @@ __global__ __launch_bounds__(kWireBlock) void k_ingest_wire(
                 } else if (vote) {
                     // stepCandidate, raft.go:1628-1648: only the response type of the campaign in progress is
                     // polled; leaders, followers and the other candidate state ignore it
-                    const u32 mine = (u32)(row[kHdrCtxLen] >> kHdrCampaignShift) & 0xFFu;
+                    const u32 mine = (u32)(line.w[kHdrCtxLen] >> kHdrCampaignShift) & 0xFFu;
                     if (mine == 0 || f.type != mine) {
                         status = kWireOtherType;
                     } else {
-                        if (f.from != 0) {
-                            for (u32 s = 0; s < S; ++s) {
-                                if (row[kHdrIds + s] == f.from) {
-                                    slot = s;
-                                    break;
-                                }
-                            }
-                        }
+                        if (f.from != 0) slot = line.find(row, S, f.from);
                         // a vote from an id without a row can change neither the result (config members
                         // only, majority.go:188-197) nor the counts (tracker.go:274-287)
                         status = slot == kWireNoSlot ? kWireNoProgress : kWireVote;
                     }
                 } else {
-                    if (f.from != 0) {
-                        for (u32 s = 0; s < S; ++s) {
-                            if (row[kHdrIds + s] == f.from) {
-                                slot = s;
-                                break;
-                            }
-                        }
-                    }
+                    if (f.from != 0) slot = line.find(row, S, f.from);
                     if (slot == kWireNoSlot) {
                         status = kWireNoProgress;
                     } else {
@@ -302,8 +321,8 @@ __global__ __launch_bounds__(kWireBlock) void k_ingest_wire(
                                 atomicMax(match + (u64)slot * stride + group, f.index);  // :1477
                             }
                         } else {
-                            const u64 want = row[kHdrCtxLen] & 0xFFu;
-                            if (want != 0 && f.ctx_len == want && f.ctx == row[kHdrCtx]) {
+                            const u64 want = line.w[kHdrCtxLen] & 0xFFu;
+                            if (want != 0 && f.ctx_len == want && f.ctx == line.w[kHdrCtx]) {
                                 flags |= kMsgFlagCtx;
                                 if (apply) or_slot_bit(acks, mbytes, group, slot);  // read_only.go:68-76
                             }
@@ -324,7 +343,7 @@ __global__ __launch_bounds__(kWireBlock) void k_ingest_wire(
             out_aux[i] = aux;
             if (slot != kWireNoSlot && status != kWireVote) {  // applied or needs-log: an event of Progress (slot, group)
                 const u32 li = index_base + (u32)i;
-                prev[li] = atomicExch(&rec[(u64)slot * stride + group].head, li + 1);
+                if (rec) prev[li] = atomicExch(&rec[(u64)slot * stride + group].head, li + 1);  // NULL: K9p links per tile
                 actions[li] = kActDeferred;
             } else {
                 actions[index_base + (u32)i] = kActDropped;

@@ -79,7 +79,8 @@ def test_create_validates_its_config_before_touching_a_device():
 
     for kw, word in ((dict(size=8), "struct_size"), (dict(groups=0), "num_groups"),
                      (dict(groups=1 << 32), "32-bit group id"), (dict(slots=0), "num_slots"),
-                     (dict(slots=65), "num_slots"), (dict(flags=8), "flags"), (dict(flags=6), "exclude each other")):
+                     (dict(slots=65), "num_slots"), (dict(flags=32), "flags"), (dict(flags=6), "exclude each other"),
+                     (dict(flags=24), "exclude each other")):
         rc, msg = create(**kw)
         assert rc == -22 and word in msg, (kw, rc, msg)
         assert h.value is None

@@ -137,10 +137,11 @@ class EngineDriver:
         return self.same(after)
 
 
+@pytest.mark.parametrize("form", [capi.FLAG_STEP_LINKED, capi.FLAG_STEP_PARTITION], ids=["linked", "partitioned"])
 @pytest.mark.parametrize("G,cap", [(1, 256), (777, 256), (4099, 1)])
-def test_figure7_transcript_on_the_engine(G, cap):
+def test_figure7_transcript_on_the_engine(G, cap, form):
     fx = f7.load()
-    with raft_amd.Engine(G, len(fx["voters"])) as e:
+    with raft_amd.Engine(G, len(fx["voters"]), flags=form) as e:
         drv = EngineDriver(e, fx, G, cap)
         assert f7.replay(fx, drv) == 21
         # every follower caught up and the entry of the leader's term is committed (raft.go:2001-2005)

@@ -59,9 +59,10 @@ def test_random_call_sequences(oracle, S, G, seed):
     wire = dict(ids=np.zeros((S, G), np.uint64), term=np.zeros(G, np.uint64), cw=np.zeros(G, np.uint64),
                 cl=np.zeros(G, np.uint8), camp=np.zeros(G, np.uint8))
 
-    # odd seeds pin rafthip_scatter_acks to its partitioned form (K5p), so that its scratch — tile counts that must be
-    # zero between calls, cursors, the skew flag — lives through a whole random sequence of other calls
-    flags = raft_amd.capi.FLAG_SCATTER_PARTITION if seed % 2 else 0
+    # odd seeds pin rafthip_scatter_acks and the Progress stepper to their partitioned forms (K5p, K9p), so that the
+    # scratch the two share — tile counts that must be zero between calls, cursors, the skew flag — lives through a
+    # whole random sequence of other calls
+    flags = (raft_amd.capi.FLAG_SCATTER_PARTITION | raft_amd.capi.FLAG_STEP_PARTITION) if seed % 2 else 0
     with raft_amd.Engine(G, S, flags=flags) as e:
         e.upload_active(sh["active"])
         e.upload_acks(sh["acks"])

@@ -10,21 +10,23 @@ from test_gpu_figure7 import EngineDriver
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("form", [raft_amd.capi.FLAG_STEP_LINKED, raft_amd.capi.FLAG_STEP_PARTITION], ids=["linked", "partitioned"])
 @pytest.mark.parametrize("G", [1, 301])
-def test_leader_app_resp_table_on_the_engine(G):
+def test_leader_app_resp_table_on_the_engine(G, form):
     t = lar.load()
     fx = lar.fixture_for_driver(t)
     for row in t["rows"]:
-        with raft_amd.Engine(G, len(fx["voters"])) as e:
+        with raft_amd.Engine(G, len(fx["voters"]), flags=form) as e:
             lar.replay_row(t, row, EngineDriver(e, fx, G, 256))
 
 
+@pytest.mark.parametrize("form", [raft_amd.capi.FLAG_STEP_LINKED, raft_amd.capi.FLAG_STEP_PARTITION], ids=["linked", "partitioned"])
 @pytest.mark.parametrize("G", [1, 130])
-def test_leader_increase_next_table_on_the_engine(G):
+def test_leader_increase_next_table_on_the_engine(G, form):
     t = lar.load_increase_next()
     fx = lar.fixture_for_driver(t)
     for row in t["rows"]:
-        with raft_amd.Engine(G, len(fx["voters"])) as e:
+        with raft_amd.Engine(G, len(fx["voters"]), flags=form) as e:
             lar.replay_increase_next(t, row, EngineDriver(e, fx, G, 256))
 
 

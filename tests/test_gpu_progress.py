@@ -14,6 +14,8 @@ from raft_amd import capi
 pytestmark = pytest.mark.gpu
 
 FX = pu.load_fixture()
+# the two forms of the stepper (include/rafthip.h): K9's global lists, K9p's partition + per-tile lists
+FORMS = {"linked": capi.FLAG_STEP_LINKED, "partitioned": capi.FLAG_STEP_PARTITION}
 KEYS = ("pstate", "next", "pending", "infl_meta", "infl_bytes", "ring_index", "ring_bytes")
 
 
@@ -46,8 +48,9 @@ def test_constants_match_the_oracle():
         po.EV_UNREACHABLE, po.EV_SNAP_STATUS, po.EV_SENT_APP, po.EV_SENT_SNAP)
 
 
+@pytest.mark.parametrize("form", FORMS)
 @pytest.mark.parametrize("k", range(len(FX["scenarios"])))
-def test_reference_scenarios(k):
+def test_reference_scenarios(k, form):
     """tests/golden/progress.json on the engine: every step as its own batch (expected
     state and actions from the reference's tests), then the whole scenario as one batch."""
     sc = FX["scenarios"][k]
@@ -59,7 +62,7 @@ def test_reference_scenarios(k):
     last = np.full(G, sc["last_index"], dtype=np.uint64)
     first = np.full(G, sc["first_index"], dtype=np.uint64)
     recs, auxs = [], []
-    with raft_amd.Engine(G, S) as e:
+    with raft_amd.Engine(G, S, flags=FORMS[form]) as e:
         upload_state(e, pl, cap, mb, active, acks, last, first)
         self_mask = np.zeros(G, dtype=active.dtype)
         self_mask[group] = 1  # the scenario's group is led from slot 0
@@ -101,16 +104,26 @@ def test_reference_scenarios(k):
 
 @pytest.mark.parametrize("S,cap,mb,hot", [(3, 4, 0, 0), (5, 4, 150, 25), (9, 1, 0, 10), (16, 8, 300, 40), (33, 3, 0, 5),
                                            (64, 2, 60, 5), (5, 0, 0, 10)])
-def test_random_streams(S, cap, mb, hot):
+@pytest.mark.parametrize("form", FORMS)
+def test_random_streams(S, cap, mb, hot, form):
+    random_streams(S, cap, mb, hot, form, 2003, 40000)
+
+
+@pytest.mark.parametrize("S,cap,mb,hot", [(5, 4, 150, 25), (9, 1, 0, 10), (33, 3, 0, 5)])
+def test_random_streams_over_several_buckets_of_tiles(S, cap, mb, hot):
+    """The partitioned form with more than one bucket of 128 tiles: 296 tiles of 1024 groups (592 of 512 at S = 33)."""
+    random_streams(S, cap, mb, hot, "partitioned", 300007, 400000)
+
+
+def random_streams(S, cap, mb, hot, form, G, n):
     rng = np.random.default_rng(1500 + S)
-    G, n = 2003, 40000
     pl = pu.random_planes(rng, S, G, cap, mb)
     msgs, aux = pu.random_events(rng, n, S, G, pl, hot_cells=hot)
     last = rng.integers(0, 1 << 20, size=G).astype(np.uint64)
     first = rng.integers(0, 1 << 19, size=G).astype(np.uint64)
     active, acks = pu.mask_planes(S, G)
     active[:] = rng.integers(0, 4, size=G)
-    with raft_amd.Engine(G, S) as e:
+    with raft_amd.Engine(G, S, flags=FORMS[form]) as e:
         upload_state(e, pl, cap, mb, active, acks, last, first)
         act = e.step_progress(msgs, aux)
         want = po.step_progress(pl, cap, mb, active, acks, last, first, msgs, aux)
@@ -131,7 +144,8 @@ def test_random_streams(S, cap, mb, hot):
         assert_state(e, pl, active, acks, last)
 
 
-def test_long_lists_are_deferred_whole():
+@pytest.mark.parametrize("form", FORMS)
+def test_long_lists_are_deferred_whole(form):
     rng = np.random.default_rng(1600)
     S, G, cap = 4, 50, 4
     pl = pu.random_planes(rng, S, G, cap, 0)
@@ -148,7 +162,7 @@ def test_long_lists_are_deferred_whole():
     last = np.full(G, 1 << 19, dtype=np.uint64)
     first = np.zeros(G, dtype=np.uint64)
     active, acks = pu.mask_planes(S, G)
-    with raft_amd.Engine(G, S) as e:
+    with raft_amd.Engine(G, S, flags=FORMS[form]) as e:
         upload_state(e, pl, cap, 0, active, acks, last, first)
         act = e.step_progress(msgs, aux)
         want = po.step_progress(pl, cap, 0, active, acks, last, first, msgs, aux)
@@ -180,9 +194,11 @@ def test_requires_config_and_rejects_bad_arguments():
         assert len(e.step_progress(m[:0])) == 0
 
 
-def test_leader_tick_with_progress_full_size():
+@pytest.mark.parametrize("form", ["auto", "linked"])
+def test_leader_tick_with_progress_full_size(form):
     """cfg5 shape: 2^20 groups x (7 voters + 2 learners), one tick = 1M sends + 3M responses
-    through rafthip_step_progress, then the commit pass; every plane vs the oracle."""
+    through rafthip_step_progress, then the commit pass; every plane vs the oracle.  A batch of this
+    size takes the partitioned form by itself ("auto")."""
     G, S, V, cap = 1 << 20, 9, 7, 4
     rng = np.random.default_rng(0x5EED0008)
     pl = pu.random_planes(rng, S, G, cap, 0)
@@ -191,7 +207,7 @@ def test_leader_tick_with_progress_full_size():
     last = pl["match"].max(axis=0) + np.uint64(16)
     first = np.maximum(pl["match"].min(axis=0), 8) - np.uint64(8)
     active, acks = pu.mask_planes(S, G)
-    with raft_amd.Engine(G, S) as e:
+    with raft_amd.Engine(G, S, flags=FORMS.get(form, 0)) as e:
         e.set_uniform_config(V)
         upload_state(e, pl, cap, 0, active, acks, last, first)
         act = e.step_progress(msgs, aux)

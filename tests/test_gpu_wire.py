@@ -180,8 +180,9 @@ def test_ingest_wire_then_commit_full_size(oracle):
         assert (wm != match).any() and wk.any()
 
 
+@pytest.mark.parametrize("form", [capi.FLAG_STEP_LINKED, capi.FLAG_STEP_PARTITION], ids=["linked", "partitioned"])
 @pytest.mark.parametrize("S,cap", [(3, 4), (9, 2), (16, 8), (40, 3)])
-def test_step_wire_feeds_the_progress_stepper(oracle, S, cap):
+def test_step_wire_feeds_the_progress_stepper(oracle, S, cap, form):
     """rafthip_step_wire = the wire decode of rafthip_ingest_wire + rafthip_step_progress on the decoded
     records: rejections probe at RejectHint when LogTerm is 0 and go to the host (status 8, later events
     of that Progress deferred) when it is not."""
@@ -210,7 +211,7 @@ def test_step_wire_feeds_the_progress_stepper(oracle, S, cap):
     active, acks = pu.mask_planes(S, G)
     want_msgs, want_aux, want_status, want_counts = oracle.decode_wire_msgs(ids, term, cw, cl, data, offsets, groups)
     assert want_counts[capi.WIRE_NEEDS_LOG] > 50 and (want_msgs["type"][want_status == 8] == capi.MSG_NEEDS_HOST).all()
-    with raft_amd.Engine(G, S) as e:
+    with raft_amd.Engine(G, S, flags=form) as e:
         e.progress_config(cap, 0)
         e.upload_match(pl["match"])
         e.upload_progress(pl["pstate"], pl["next"], pl["pending"])

@@ -281,7 +281,7 @@ def main():
                   atomics_per_unit=1)
         del data, offsets, d_data, d_off, d_grp
     # per-peer replication state (K9): sends + responses in stream order per Progress
-    if not args.only or args.only in "k_progress_link + k_progress_apply (K9)":
+    if not args.only or args.only in "k_progress_link + k_progress_apply (K9) (K9p)":
         import progress_util as pu
         cap = 4
         pl = pu.random_planes(rng, Sv, G, cap, 0)
@@ -290,18 +290,20 @@ def main():
         d_aux = torch.from_numpy(aux.view(np.int64)).to(dev)
         d_act = torch.zeros(N, dtype=torch.uint8, device=dev)
         L = raft_amd.load_library()
-        with raft_amd.Engine(G, Sv, stream=stream.cuda_stream) as e:
-            e.set_uniform_config(7)
-            e.progress_config(cap, 0)
-            e.upload_match(pl["match"])
-            e.upload_progress(pl["pstate"], pl["next"], pl["pending"])
-            e.upload_inflights(pl["infl_meta"], pl["infl_bytes"], pl["ring_index"], pl["ring_bytes"])
-            e.upload_term_range(np.zeros(G, dtype=np.uint64), pl["match"].max(axis=0) + np.uint64(16))
-            # record 16 + aux 8 + link 4+4 + action 1+1 + the 32-byte Progress record read and written
-            # back + Match read (written only when it moves) = 106
-            timed("k_progress_link + k_progress_apply, random cells (K9)", "event", N, 106,
-                  lambda: L.rafthip_step_progress(e._h, d_ev.data_ptr(), d_aux.data_ptr(), N, d_act.data_ptr()),
-                  atomics_per_unit=1)
+        for flag, label in ((raft_amd.capi.FLAG_STEP_LINKED, "k_progress_link + k_progress_apply, random cells (K9)"),
+                            (raft_amd.capi.FLAG_STEP_PARTITION, "count + scan + 2 partition passes + k_prog_part_apply, the same events (K9p)")):
+            with raft_amd.Engine(G, Sv, stream=stream.cuda_stream, flags=flag) as e:
+                e.set_uniform_config(7)
+                e.progress_config(cap, 0)
+                e.upload_match(pl["match"])
+                e.upload_progress(pl["pstate"], pl["next"], pl["pending"])
+                e.upload_inflights(pl["infl_meta"], pl["infl_bytes"], pl["ring_index"], pl["ring_bytes"])
+                e.upload_term_range(np.zeros(G, dtype=np.uint64), pl["match"].max(axis=0) + np.uint64(16))
+                # record 16 + aux 8 + link 4+4 + action 1+1 + the 32-byte Progress record read and written
+                # back + Match read (written only when it moves) = 106
+                timed(label, "event", N, 106,
+                      lambda: L.rafthip_step_progress(e._h, d_ev.data_ptr(), d_aux.data_ptr(), N, d_act.data_ptr()),
+                      atomics_per_unit=1)
         del pl, ev, aux, d_ev, d_aux, d_act
     # dense tick through the Progress stepper (K9d): the same 4*G acks as a plane + heartbeat masks
     if not args.only or args.only in "k_progress_dense (K9d)":
