@@ -250,14 +250,9 @@ __device__ __forceinline__ MsgFields load_msg(const Msg* msgs, u64 i) {
     return f;
 }
 
-__global__ __launch_bounds__(kBlock) void k_progress_link(const Msg* __restrict__ msgs, u32 n, u64 G, u32 S,
-                                                          u64 stride, ProgRec* __restrict__ rec,
-                                                          u32* __restrict__ prev, u64* __restrict__ term_last,
-                                                          uint8_t* __restrict__ actions,
-                                                          const u32* __restrict__ only_if /* NULL, or a device flag: run only when set (K9p's fallback) */) {
-    const u32 i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    if (only_if && !only_if[0]) return;
+__device__ __forceinline__ void progress_link_one(u32 i, const Msg* __restrict__ msgs, u64 G, u32 S, u64 stride,
+                                                  ProgRec* __restrict__ rec, u32* __restrict__ prev,
+                                                  u64* __restrict__ term_last, uint8_t* __restrict__ actions) {
     const MsgFields f = load_msg(msgs, i);
     uint8_t act;
     if (f.type == kMsgAppended) {
@@ -276,17 +271,32 @@ __global__ __launch_bounds__(kBlock) void k_progress_link(const Msg* __restrict_
     actions[i] = act;
 }
 
-__global__ __launch_bounds__(kBlock) void k_progress_apply(const Msg* __restrict__ msgs,
-                                                           const u64* __restrict__ aux, u32 n, u64 G, u32 S,
-                                                           ProgPlanes pl, const u32* __restrict__ prev,
-                                                           void* __restrict__ active, void* __restrict__ acks,
-                                                           int mbytes, const u64* __restrict__ term_last,
-                                                           const u64* __restrict__ first_index,
-                                                           uint8_t* __restrict__ actions,
-                                                           const u32* __restrict__ only_if /* as in k_progress_link */) {
+__global__ __launch_bounds__(kBlock) void k_progress_link(const Msg* __restrict__ msgs, u32 n, u64 G, u32 S,
+                                                          u64 stride, ProgRec* __restrict__ rec,
+                                                          u32* __restrict__ prev, u64* __restrict__ term_last,
+                                                          uint8_t* __restrict__ actions) {
     const u32 i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    if (only_if && !only_if[0]) return;
+    if (i < n) progress_link_one(i, msgs, G, S, stride, rec, prev, term_last, actions);
+}
+
+// K9p's fallback (progress_part.h): the same pass behind a device flag, as a grid-stride grid — when the flag is
+// clear, the usual case, a modest grid leaves at once (one workgroup per 256 events: 17 us of empty launches at 2^24)
+constexpr u32 kProgFlaggedGrid = 8192;
+__global__ __launch_bounds__(kBlock) void k_progress_link_flagged(const Msg* __restrict__ msgs, u32 n, u64 G, u32 S,
+                                                                  u64 stride, ProgRec* __restrict__ rec,
+                                                                  u32* __restrict__ prev, u64* __restrict__ term_last,
+                                                                  uint8_t* __restrict__ actions,
+                                                                  const u32* __restrict__ flag) {
+    if (!flag[0]) return;
+    for (u64 i = (u64)blockIdx.x * kBlock + threadIdx.x; i < n; i += (u64)gridDim.x * kBlock)
+        progress_link_one((u32)i, msgs, G, S, stride, rec, prev, term_last, actions);
+}
+
+__device__ __forceinline__ void progress_apply_one(u32 i, const Msg* __restrict__ msgs, const u64* __restrict__ aux, u32 n,
+                                                   u64 G, u32 S, const ProgPlanes& pl, const u32* __restrict__ prev,
+                                                   void* __restrict__ active, void* __restrict__ acks, int mbytes,
+                                                   const u64* __restrict__ term_last, const u64* __restrict__ first_index,
+                                                   uint8_t* __restrict__ actions) {
     const MsgFields own = load_msg(msgs, i);
     if (!prog_event_type(own.type) || (u64)own.group >= G || own.slot >= S) return;
     const u64 cell = (u64)own.slot * pl.stride + own.group;
@@ -344,6 +354,30 @@ __global__ __launch_bounds__(kBlock) void k_progress_apply(const Msg* __restrict
     store_vec<u64, 2>(rw + 2, w1);
     if (p.active) or_slot_bit(active, mbytes, own.group, own.slot);
     if (p.read_ack) or_slot_bit(acks, mbytes, own.group, own.slot);
+}
+
+__global__ __launch_bounds__(kBlock) void k_progress_apply(const Msg* __restrict__ msgs,
+                                                           const u64* __restrict__ aux, u32 n, u64 G, u32 S,
+                                                           ProgPlanes pl, const u32* __restrict__ prev,
+                                                           void* __restrict__ active, void* __restrict__ acks,
+                                                           int mbytes, const u64* __restrict__ term_last,
+                                                           const u64* __restrict__ first_index,
+                                                           uint8_t* __restrict__ actions) {
+    const u32 i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) progress_apply_one(i, msgs, aux, n, G, S, pl, prev, active, acks, mbytes, term_last, first_index, actions);
+}
+
+__global__ __launch_bounds__(kBlock) void k_progress_apply_flagged(const Msg* __restrict__ msgs,
+                                                                   const u64* __restrict__ aux, u32 n, u64 G, u32 S,
+                                                                   ProgPlanes pl, const u32* __restrict__ prev,
+                                                                   void* __restrict__ active, void* __restrict__ acks,
+                                                                   int mbytes, const u64* __restrict__ term_last,
+                                                                   const u64* __restrict__ first_index,
+                                                                   uint8_t* __restrict__ actions,
+                                                                   const u32* __restrict__ flag) {
+    if (!flag[0]) return;
+    for (u64 i = (u64)blockIdx.x * kBlock + threadIdx.x; i < n; i += (u64)gridDim.x * kBlock)
+        progress_apply_one((u32)i, msgs, aux, n, G, S, pl, prev, active, acks, mbytes, term_last, first_index, actions);
 }
 
 // K9d — the same stepping when a tick's responses are dense: an ack plane

@@ -1761,12 +1761,13 @@ static int progress_partitioned(rafthip_engine* e, const Msg* d_msgs, const u64*
     HIP_TRY(hipGetLastError());
     // a batch the scan found piled onto one tile: K9's two passes over the original records (decided on the device;
     // the usual case is two grids that leave at once)
-    const u32 blocks = (u32)((n + kBlock - 1) / kBlock);
+    const u64 want = (n + kBlock - 1) / kBlock;
+    const u32 blocks = (u32)(want < kProgFlaggedGrid ? want : kProgFlaggedGrid);
     e->heads_dirty = true;
-    hipLaunchKernelGGL(k_progress_link, dim3(blocks), dim3(kBlock), 0, st, d_msgs, (u32)n, e->G, e->S, e->stride, e->pp.rec, prev,
-                       e->term_last, d_act, static_cast<const u32*>(pb.flag));
+    hipLaunchKernelGGL(k_progress_link_flagged, dim3(blocks), dim3(kBlock), 0, st, d_msgs, (u32)n, e->G, e->S, e->stride, e->pp.rec,
+                       prev, e->term_last, d_act, static_cast<const u32*>(pb.flag));
     HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(k_progress_apply, dim3(blocks), dim3(kBlock), 0, st, d_msgs, d_aux, (u32)n, e->G, e->S, e->pp,
+    hipLaunchKernelGGL(k_progress_apply_flagged, dim3(blocks), dim3(kBlock), 0, st, d_msgs, d_aux, (u32)n, e->G, e->S, e->pp,
                        static_cast<const u32*>(prev), e->active, e->acks, e->mbytes, static_cast<const u64*>(e->term_last),
                        static_cast<const u64*>(e->first_index), d_act, static_cast<const u32*>(pb.flag));
     HIP_TRY(hipGetLastError());
@@ -1786,19 +1787,18 @@ static int progress_passes(rafthip_engine* e, const Msg* d_msgs, const u64* d_au
     u32* prev = static_cast<u32*>(e->stage_buf[kStagePrev]);
     if (part && !linked) return progress_partitioned(e, d_msgs, d_aux, n, d_act, prev);
     const u32 blocks = (u32)((n + kBlock - 1) / kBlock);
-    const u32* const always = nullptr;
     if (!linked) {
         int rc2 = clear_stale_heads(e);
         if (rc2) return rc2;
         e->heads_dirty = true;  // until the apply pass is on the stream
         hipLaunchKernelGGL(k_progress_link, dim3(blocks), dim3(kBlock), 0, e->stream, d_msgs, (u32)n, e->G, e->S,
-                           e->stride, e->pp.rec, prev, e->term_last, d_act, always);
+                           e->stride, e->pp.rec, prev, e->term_last, d_act);
         HIP_TRY(hipGetLastError());
     }
     e->pp.match = e->match;
     hipLaunchKernelGGL(k_progress_apply, dim3(blocks), dim3(kBlock), 0, e->stream, d_msgs, d_aux, (u32)n, e->G, e->S,
                        e->pp, static_cast<const u32*>(prev), e->active, e->acks, e->mbytes,
-                       static_cast<const u64*>(e->term_last), static_cast<const u64*>(e->first_index), d_act, always);
+                       static_cast<const u64*>(e->term_last), static_cast<const u64*>(e->first_index), d_act);
     HIP_TRY(hipGetLastError());
     e->heads_dirty = false;
     return RAFTHIP_OK;

@@ -115,6 +115,12 @@ def test_random_streams_over_several_buckets_of_tiles(S, cap, mb, hot):
     random_streams(S, cap, mb, hot, "partitioned", 300007, 400000)
 
 
+def test_a_batch_piled_onto_one_tile_falls_back_to_the_lists():
+    """More than 2^17 events in one tile of 1024 groups: the partitioned form's scan raises its flag on the device and
+    K9's link and apply passes step the batch (the grid-stride forms behind the flag)."""
+    random_streams(9, 4, 0, 0, "partitioned", 1000, 140000)
+
+
 def random_streams(S, cap, mb, hot, form, G, n):
     rng = np.random.default_rng(1500 + S)
     pl = pu.random_planes(rng, S, G, cap, mb)
