@@ -1702,7 +1702,7 @@ int rafthip_upload_first_index(rafthip_engine* e, uint64_t first, uint64_t count
 
 // Tile of K9p for this engine: the largest power of two of groups (at most 1024) whose S cell counters fit 64 KB of LDS.
 static u32 prog_part_tile_shift(const rafthip_engine* e) {
-    u32 shift = 10;
+    u32 shift = 10;  // 256- and 512-group tiles measured: the same within 2 % (1460 / 1429 / 1466 us per 2^24 events)
     while (((size_t)e->S << shift) * sizeof(u32) > 64u * 1024u) --shift;
     return shift;
 }
