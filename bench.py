@@ -403,6 +403,116 @@ def run_cfg5(raft_amd, torch, dev, local_rank, stream, rank, world, reps):
 
 # ---------------------------------------------------------------------------------------------
 
+def run_tick(raft_amd, torch, dev, local_rank, stream, reps):
+    """One leader-side tick at BASELINE cfg5's per-GPU scale (tools/tick_bench.py): 2^22 groups x
+    (7 voters + 2 learners), 2^24 serialized responses resident on the device -> rafthip_step_wire (decode, term gate,
+    Progress lookup, Progress / Inflights stepping; the partitioned stepper K9p at this size), rafthip_commit_advance,
+    rafthip_plan_appends, rafthip_emit_heartbeats, rafthip_check_quorum.  The first round is checked against the
+    oracle on the sub-stream of the first 4096 groups: status, action bytes, Progress state, Match."""
+    import progress_util as pu
+    import wire_util as wu
+    from oracle import pyoracle as po
+    G, S, V, cap = 1 << 22, 9, 7, 4
+    N = 4 * G
+    rng = np.random.default_rng(0x5EED0009)
+    pl = pu.random_planes(rng, S, G, cap, 0)
+    pl["pstate"][:] = 1  # steady state: every peer replicating, nothing paused
+    ids = np.ascontiguousarray((np.arange(S, dtype=np.uint64)[:, None] + np.uint64(1)) * np.uint64(0x10001)
+                               + rng.integers(0, 1 << 16, size=G, dtype=np.uint64)[None, :] * np.uint64(1 << 20))
+    term = rng.integers(1, 1 << 20, size=G).astype(np.uint64)
+    ctx = rng.integers(1, 1 << 63, size=G, dtype=np.uint64)
+    groups = rng.integers(0, G, size=N).astype(np.uint32)
+    slots = rng.integers(0, S, size=N)
+    data, offsets = wu.encode_responses(rng, ids[slots, groups], term[groups],
+                                        pl["match"][slots, groups] + rng.integers(1, 64, size=N).astype(np.uint64), ctx[groups])
+    last = pl["match"].max(axis=0) + np.uint64(128)
+    d_data = torch.from_numpy(data).to(dev)
+    d_off = torch.from_numpy(offsets.view(np.int64)).to(dev)
+    d_grp = torch.from_numpy(groups.view(np.int32)).to(dev)
+    d_status = torch.zeros(N, dtype=torch.uint8, device=dev)
+    d_act = torch.zeros(N, dtype=torch.uint8, device=dev)
+    d_plan = torch.empty((S, G), dtype=torch.uint8, device=dev)
+    d_next = torch.empty((S, G), dtype=torch.int64, device=dev)
+    d_hbytes = torch.empty((S, G, 72), dtype=torch.uint8, device=dev)
+    d_hlen = torch.empty((S, G), dtype=torch.uint8, device=dev)
+    L = raft_amd.load_library()
+    ones = np.ones(G, dtype=np.uint16)
+    with raft_amd.Engine(G, S, device=local_rank, stream=stream.cuda_stream) as e:
+        e.set_uniform_config(V)
+        e.progress_config(cap, 0)
+        e.upload_ids(ids)
+        e.upload_term(term)
+        e.upload_read_ctx(ctx, np.full(G, 8, dtype=np.uint8))
+        e.upload_self(ones)
+
+        def reset():
+            e.upload_match(pl["match"])
+            e.upload_progress(pl["pstate"], pl["next"], pl["pending"])
+            e.upload_inflights(pl["infl_meta"], pl["infl_bytes"], pl["ring_index"], pl["ring_bytes"])
+            e.upload_commit(np.zeros(G, dtype=np.uint64))
+            e.upload_term_range(np.zeros(G, dtype=np.uint64), last)
+            e.upload_active(ones)
+            e.upload_acks(np.zeros(G, dtype=np.uint16))
+
+        def ok(rc):
+            if rc != 0:
+                raise RuntimeError(L.rafthip_last_error().decode())
+
+        stages = [
+            ("step_wire", lambda: ok(L.rafthip_step_wire(e._h, d_data.data_ptr(), d_off.data_ptr(), d_grp.data_ptr(), N, None,
+                                                         d_status.data_ptr(), None, d_act.data_ptr()))),
+            ("commit_advance", lambda: e.commit_advance(max_pairs=0)),
+            ("plan_appends", lambda: ok(L.rafthip_plan_appends(e._h, 0, G, 1, d_plan.data_ptr(), d_next.data_ptr(), G))),
+            ("emit_heartbeats", lambda: ok(L.rafthip_emit_heartbeats(e._h, 0, G, d_hbytes.data_ptr(), d_hlen.data_ptr()))),
+            ("check_quorum", lambda: e.check_quorum()),
+        ]
+        times = {k: [] for k, _ in stages}
+        checked = 0
+        with torch.cuda.stream(stream):
+            for it in range(reps + 1):
+                reset()
+                torch.cuda.synchronize()
+                for name, fn in stages:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(stream)
+                    fn()
+                    e1.record(stream)
+                    e1.synchronize()
+                    if it:
+                        times[name].append(e0.elapsed_time(e1))
+                    if it == 0 and name == "step_wire":
+                        # oracle = checker: the responses of the first n groups, in stream order
+                        n = 4096
+                        sel = np.flatnonzero(groups < n)
+                        o64 = offsets.astype(np.int64)
+                        sub = np.concatenate([data[o64[i]:o64[i + 1]] for i in sel])
+                        sub_off = np.zeros(len(sel) + 1, dtype=np.uint64)
+                        np.cumsum((o64[sel + 1] - o64[sel]).astype(np.uint64), out=sub_off[1:])
+                        spl = {k: np.ascontiguousarray(v[..., :n]) for k, v in pl.items()}
+                        act_m, ack_m = ones[:n].copy(), np.zeros(n, dtype=np.uint16)
+                        wm, wa, wst, _ = po.decode_wire_msgs(np.ascontiguousarray(ids[:, :n]), term[:n].copy(), ctx[:n].copy(),
+                                                             np.full(n, 8, dtype=np.uint8), sub, sub_off,
+                                                             np.ascontiguousarray(groups[sel]))
+                        want = po.step_progress(spl, cap, 0, act_m, ack_m, last[:n].copy(), np.zeros(n, dtype=np.uint64), wm, wa)
+                        sel_t = torch.from_numpy(sel).to(dev)
+                        got_act = d_act[sel_t].cpu().numpy()
+                        got_st = d_status[sel_t].cpu().numpy()
+                        got = e.read_progress(0, n)
+                        if not (np.array_equal(got_st, wst) and np.array_equal(got_act, want)
+                                and all(np.array_equal(got[k], spl[k]) for k in ("pstate", "next", "pending", "infl_meta", "infl_bytes"))
+                                and np.array_equal(e.read_match(0, n), spl["match"])):
+                            raise SystemExit("bench tick: GPU result differs from the oracle")
+                        checked = int(len(sel))
+        out = {k: round(float(np.median(v)), 4) for k, v in times.items()}
+        tick = sum(out.values())
+        return {"groups": G, "slots": S, "messages": N, "bytes_per_message": round(len(data) / N, 1), "stage_ms": out,
+                "tick_ms": round(tick, 4), "messages_per_s": N / tick * 1e3,
+                "applied": int((d_status == 0).sum().item()), "updated": int(((d_act & 2) != 0).sum().item()),
+                "heartbeats_out": int((d_hlen != 0).sum().item()),
+                "stepper": "K9p (partition by tile, sort by cell, apply); rafthip_step_wire picks it from 2^18 events",
+                "oracle_checked_messages": checked}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -821,6 +931,12 @@ def main():
             except Exception as ex:
                 extra[name] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
             torch.cuda.empty_cache()
+        # the rows SURVEY.md §8 marks "next" (f2, f3, f4), as one leader-side tick from serialized bytes in to bytes out
+        try:
+            extra["tick_4M_groups_16M_responses"] = run_tick(raft_amd, torch, dev, local_rank, stream, 3)
+        except Exception as ex:
+            extra["tick_4M_groups_16M_responses"] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
+        torch.cuda.empty_cache()
 
     if rank == 0:
         total_groups = world * K * G_BATCH

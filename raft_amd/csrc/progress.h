@@ -68,14 +68,21 @@ __host__ __device__ __forceinline__ u32 rec_meta(u32 start, u32 count, u32 pstat
     return (start & 0x3FFFu) | ((count & 0x7FFFu) << 14) | (pstate << 29);
 }
 
+// One entry of an Inflights ring: inflight{index, bytes} (tracker/inflights.go:18-21).
+struct RingEntry {
+    u64 index, bytes;
+};
 struct ProgPlanes {
     u64* match;        // [S][stride]
     ProgRec* rec;      // [S][stride]
-    u64* ring_index;   // [cap][S][stride]
-    u64* ring_bytes;   // [cap][S][stride]
+    // Inflights.buffer of every Progress: [S][stride][max(cap, 1)] entries, the ring of one Progress contiguous.
+    // (Rounds 1-2 kept two planes [entry][slot][group]: FreeLE's walk then read one 8-byte word per line and entry —
+    // five lines per ack at cap 4, a TLB entry apart at larger caps; now it is one 16-byte load per entry from one
+    // or a few adjacent lines.  The C ABI still speaks [entry][slot][group] planes: k_ring_pack / k_ring_unpack.)
+    RingEntry* ring;
     u64 stride;
-    u64 plane;         // S * stride
     u32 cap;           // Inflights.size
+    u32 ring_len;      // max(cap, 1): entries per Progress in `ring`
     u64 max_bytes;     // Inflights.maxBytes
 };
 
@@ -115,16 +122,24 @@ __device__ __forceinline__ bool prog_is_paused(const Prog& p) {  // progress.go:
     return p.state == kStateSnapshot ? true : p.paused != 0;
 }
 
+__device__ __forceinline__ RingEntry ring_load(const RingEntry* p) {
+    const Vec<u64, 2> v = load_vec<u64, 2>(reinterpret_cast<const u64*>(p));
+    return RingEntry{v.v[0], v.v[1]};
+}
+
 // Inflights.FreeLE, inflights.go:98-128, on the cell's ring in global memory.
 __device__ __forceinline__ void infl_free_le(Prog& p, const ProgPlanes& pl, u64 cell, u64 to) {
-    if (p.icount == 0 || to < pl.ring_index[(u64)p.istart * pl.plane + cell]) return;
+    if (p.icount == 0) return;
+    const RingEntry* ring = pl.ring + cell * pl.ring_len;
     u32 idx = p.istart, i = 0;
     u64 bytes = 0;
     for (; i < p.icount; ++i) {
-        if (to < pl.ring_index[(u64)idx * pl.plane + cell]) break;
-        bytes += pl.ring_bytes[(u64)idx * pl.plane + cell];
+        const RingEntry en = ring_load(ring + idx);
+        if (to < en.index) break;
+        bytes += en.bytes;
         if (++idx >= pl.cap) idx -= pl.cap;
     }
+    if (i == 0) return;  // out of the left side of the window (inflights.go:99-102)
     p.icount -= i;
     p.ibytes -= bytes;
     p.istart = idx;
@@ -206,8 +221,10 @@ __device__ __forceinline__ uint8_t prog_step(Prog& p, const ProgPlanes& pl, u64 
                     p.next = index + 1;  // OptimisticUpdate
                     u32 pos = p.istart + p.icount;
                     if (pos >= pl.cap) pos -= pl.cap;
-                    pl.ring_index[(u64)pos * pl.plane + cell] = index;
-                    pl.ring_bytes[(u64)pos * pl.plane + cell] = aux;
+                    Vec<u64, 2> en;
+                    en.v[0] = index;
+                    en.v[1] = aux;
+                    store_vec<u64, 2>(reinterpret_cast<u64*>(pl.ring + cell * pl.ring_len + pos), en);
                     p.icount++;
                     p.ibytes += aux;
                 }
@@ -598,6 +615,34 @@ __global__ __launch_bounds__(kBlock) void k_progress_unpack(const ProgRec* __res
         meta[o] = (r.meta & 0x3FFFu) | (((r.meta >> 14) & 0x7FFFu) << 16);
         bytes[o] = r.ibytes;
     }
+}
+
+// Inflights rings between the ABI's [entry][slot][group] planes (row pitch `pitch`, group 0 = `first`) and the
+// engine's [slot][group][entry] records.
+__global__ __launch_bounds__(kBlock) void k_ring_pack(RingEntry* __restrict__ ring, u64 stride, u64 first, u64 count, u32 S,
+                                                      u32 ring_len, const u64* __restrict__ index,
+                                                      const u64* __restrict__ bytes, u64 pitch) {
+    const u64 g = (u64)blockIdx.x * kBlock + threadIdx.x;
+    if (g >= count) return;
+    for (u32 s = 0; s < S; ++s)
+        for (u32 k = 0; k < ring_len; ++k) {
+            Vec<u64, 2> en;
+            en.v[0] = index[((u64)k * S + s) * pitch + g];
+            en.v[1] = bytes[((u64)k * S + s) * pitch + g];
+            store_vec<u64, 2>(reinterpret_cast<u64*>(ring + ((u64)s * stride + first + g) * ring_len + k), en);
+        }
+}
+__global__ __launch_bounds__(kBlock) void k_ring_unpack(const RingEntry* __restrict__ ring, u64 stride, u64 first, u64 count,
+                                                        u32 S, u32 ring_len, u64* __restrict__ index /* may be NULL */,
+                                                        u64* __restrict__ bytes /* may be NULL */, u64 pitch) {
+    const u64 g = (u64)blockIdx.x * kBlock + threadIdx.x;
+    if (g >= count) return;
+    for (u32 s = 0; s < S; ++s)
+        for (u32 k = 0; k < ring_len; ++k) {
+            const RingEntry en = ring_load(ring + ((u64)s * stride + first + g) * ring_len + k);
+            if (index) index[((u64)k * S + s) * pitch + g] = en.index;
+            if (bytes) bytes[((u64)k * S + s) * pitch + g] = en.bytes;
+        }
 }
 
 }  // namespace rafthip

@@ -788,7 +788,7 @@ int rafthip_destroy(rafthip_engine* e) {
                     e->active,  e->acks,       e->vote_result,  e->granted,  e->rejected, e->qactive,
                     e->ack_result, e->rep_bits, e->packed,      e->rep_counts, e->rep_super, e->ack_buf,
                     e->d_rejected, e->self_mask, e->term_first, e->term_last, e->hb_commit, e->in_term,
-                    e->wire_hdr, e->d_wire_counts, e->pp.rec, e->pp.ring_index, e->pp.ring_bytes,
+                    e->wire_hdr, e->d_wire_counts, e->pp.rec, e->pp.ring,
                     e->first_index, e->vote_first, e->part_a, e->part_b, e->part_words};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
@@ -1537,18 +1537,17 @@ int rafthip_progress_config(rafthip_engine* e, uint32_t max_inflight, uint64_t m
     }
     DeviceGuard guard(e->device);
     const size_t cells = (size_t)e->S * e->stride;
-    const size_t ring = (size_t)(max_inflight ? max_inflight : 1) * cells * sizeof(u64);
+    const size_t ring = (size_t)(max_inflight ? max_inflight : 1) * cells * sizeof(RingEntry);
     int rc;
     if ((rc = ensure(e, e->pp.rec, cells * sizeof(ProgRec)))) return rc;
-    if ((rc = ensure(e, e->pp.ring_index, ring))) return rc;
-    if ((rc = ensure(e, e->pp.ring_bytes, ring))) return rc;
+    if ((rc = ensure(e, e->pp.ring, ring))) return rc;
     if ((rc = ensure(e, e->first_index, (size_t)e->stride * sizeof(u64)))) return rc;
     if ((rc = ensure(e, e->term_last, (size_t)e->stride * sizeof(u64)))) return rc;
     if ((rc = ensure(e, e->term_first, (size_t)e->stride * sizeof(u64)))) return rc;
     e->pp.match = e->match;
     e->pp.stride = e->stride;
-    e->pp.plane = (u64)cells;
     e->pp.cap = max_inflight;
+    e->pp.ring_len = max_inflight ? max_inflight : 1;
     e->pp.max_bytes = max_inflight_bytes;
     e->prog = true;
     return RAFTHIP_OK;
@@ -1665,8 +1664,18 @@ int rafthip_upload_inflights(rafthip_engine* e, uint64_t first, uint64_t count, 
                        e->stream, e->pp.rec, st, (u64)first, (u64)count, e->S, static_cast<const u32*>(t_meta),
                        static_cast<const u64*>(t_bytes));
     HIP_TRY(hipGetLastError());
-    if ((rc = copy_rows(e, e->pp.ring_index + first, st * 8, ring_index, src_stride * 8, count * 8, rows))) return rc;
-    if ((rc = copy_rows(e, e->pp.ring_bytes + first, st * 8, ring_bytes, src_stride * 8, count * 8, rows))) return rc;
+    // the rings: the ABI's [entry][slot][group] planes -> one contiguous ring per Progress
+    TempPlanes tr;
+    const size_t plane_b = (size_t)rows * count * 8;
+    if ((rc = tr.alloc(2 * plane_b))) return rc;
+    u64* t_ri = reinterpret_cast<u64*>(tr.base);
+    u64* t_rb = reinterpret_cast<u64*>(tr.base + plane_b);
+    if ((rc = copy_rows(e, t_ri, count * 8, ring_index, src_stride * 8, count * 8, rows))) return rc;
+    if ((rc = copy_rows(e, t_rb, count * 8, ring_bytes, src_stride * 8, count * 8, rows))) return rc;
+    hipLaunchKernelGGL(k_ring_pack, dim3((u32)((count + kBlock - 1) / kBlock)), dim3(kBlock), 0, e->stream, e->pp.ring, st,
+                       (u64)first, (u64)count, e->S, e->pp.ring_len, static_cast<const u64*>(t_ri),
+                       static_cast<const u64*>(t_rb), (u64)count);
+    HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(e->stream));
     e->stats.bytes_uploaded += count * (e->S * 12 + rows * 16);
     return RAFTHIP_OK;
@@ -1678,11 +1687,19 @@ int rafthip_read_inflights(rafthip_engine* e, uint64_t first, uint64_t count, ui
     if (rc || (rc = check_range(e, first, count))) return rc;
     if (dst_stride < count) return fail(RAFTHIP_EINVAL, "dst_stride %llu < count %llu", (u64)dst_stride, (u64)count);
     DeviceGuard guard(e->device);
-    const u64 st = e->stride, rows = (u64)(e->pp.cap ? e->pp.cap : 1) * e->S;
-    if (ring_index && (rc = copy_rows(e, ring_index, dst_stride * 8, e->pp.ring_index + first, st * 8, count * 8, rows)))
-        return rc;
-    if (ring_bytes && (rc = copy_rows(e, ring_bytes, dst_stride * 8, e->pp.ring_bytes + first, st * 8, count * 8, rows)))
-        return rc;
+    if (count == 0 || (!ring_index && !ring_bytes)) return RAFTHIP_OK;
+    const u64 st = e->stride, rows = (u64)e->pp.ring_len * e->S;
+    TempPlanes tr;
+    const size_t plane_b = (size_t)rows * count * 8;
+    if ((rc = tr.alloc(2 * plane_b))) return rc;
+    u64* t_ri = ring_index ? reinterpret_cast<u64*>(tr.base) : nullptr;
+    u64* t_rb = ring_bytes ? reinterpret_cast<u64*>(tr.base + plane_b) : nullptr;
+    hipLaunchKernelGGL(k_ring_unpack, dim3((u32)((count + kBlock - 1) / kBlock)), dim3(kBlock), 0, e->stream,
+                       static_cast<const RingEntry*>(e->pp.ring), st, (u64)first, (u64)count, e->S, e->pp.ring_len, t_ri, t_rb,
+                       (u64)count);
+    HIP_TRY(hipGetLastError());
+    if (ring_index && (rc = copy_rows(e, ring_index, dst_stride * 8, t_ri, count * 8, count * 8, rows))) return rc;
+    if (ring_bytes && (rc = copy_rows(e, ring_bytes, dst_stride * 8, t_rb, count * 8, count * 8, rows))) return rc;
     HIP_TRY(hipStreamSynchronize(e->stream));
     e->stats.bytes_downloaded += count * rows * ((ring_index ? 8 : 0) + (ring_bytes ? 8 : 0));
     return RAFTHIP_OK;

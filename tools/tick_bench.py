@@ -66,6 +66,8 @@ def main():
         def reset():
             e.upload_match(pl["match"])
             e.upload_progress(pl["pstate"], pl["next"], pl["pending"])
+            if not os.environ.get("TICK_DRAINED_RINGS"):  # (rounds 1-2 measured every round after the first on drained Inflights)
+                e.upload_inflights(pl["infl_meta"], pl["infl_bytes"], pl["ring_index"], pl["ring_bytes"])
             e.upload_commit(np.zeros(G, dtype=np.uint64))
             e.upload_term_range(np.zeros(G, dtype=np.uint64), last)
             e.upload_active(np.ones(G, dtype=np.uint16))
