@@ -45,21 +45,25 @@ struct WireFields {
     u64 ctx_len;
 };
 
+// Byte sources of the parser.  Positions are the reader's own type: 64-bit offsets into the caller's buffer for
+// global memory, 32-bit offsets into the staged window for LDS — the byte loop is all position arithmetic and
+// compares, and in 64 bits it cost twice the VALU instructions and spilled its exec masks (round 3).
 struct GlobalBytes {
+    using pos_t = i64;
     const uint8_t* p;
     __device__ __forceinline__ u32 operator()(i64 pos) const { return p[pos]; }
 };
 struct LdsBytes {
-    const uint8_t* sm;  // sm[0] holds byte `base`
-    i64 base;
-    __device__ __forceinline__ u32 operator()(i64 pos) const { return sm[pos - base]; }
+    using pos_t = u32;
+    const uint8_t* sm;  // sm[i] holds byte i of the window
+    __device__ __forceinline__ u32 operator()(u32 pos) const { return sm[pos]; }
 };
 
 // The varint loop every field of Unmarshal uses (e.g. raft.pb.go:1807-1820):
 // at most 10 bytes, bits past 63 are shifted out, running off the buffer or an
 // 11th byte is an error.
 template <class R>
-__device__ __forceinline__ bool wire_varint(const R& rd, i64& pos, i64 end, u64& v) {
+__device__ __forceinline__ bool wire_varint(const R& rd, typename R::pos_t& pos, typename R::pos_t end, u64& v) {
     v = 0;
     for (u32 shift = 0;; shift += 7) {
         if (shift >= 64) return false;  // ErrIntOverflowRaft
@@ -73,8 +77,8 @@ __device__ __forceinline__ bool wire_varint(const R& rd, i64& pos, i64 end, u64&
 // skipRaft (raft.pb.go:3027-3104) on [pos, end): skips one unknown field,
 // groups included.  The caller's `iNdEx + skippy > l` check is folded in.
 template <class R>
-__device__ bool wire_skip(const R& rd, i64& pos, i64 end) {
-    i64 i = pos;
+__device__ bool wire_skip(const R& rd, typename R::pos_t& pos, typename R::pos_t end) {
+    typename R::pos_t i = pos;
     int depth = 0;
     while (i < end) {
         u64 wire;
@@ -89,8 +93,8 @@ __device__ bool wire_skip(const R& rd, i64& pos, i64 end) {
             case 2: {
                 u64 len;
                 if (!wire_varint(rd, i, end, len)) return false;
-                if ((i64)len < 0 || (i64)len > end - i) return false;  // ErrInvalidLengthRaft / past the end
-                i += (i64)len;
+                if (len > (u64)(end - i)) return false;  // ErrInvalidLengthRaft (negative as int) / past the end
+                i += (typename R::pos_t)len;
                 break;
             }
             case 3: ++depth; break;
@@ -114,13 +118,13 @@ __device__ bool wire_skip(const R& rd, i64& pos, i64 end) {
 // error.  Nested messages (fields 7, 9, 14) are measured, not decoded: a
 // non-empty one sets `nested` and the message is left to the host.
 template <class R>
-__device__ bool wire_parse(const R& rd, i64 pos, i64 end, WireFields& f) {
+__device__ bool wire_parse(const R& rd, typename R::pos_t pos, typename R::pos_t end, WireFields& f) {
     f.type = 0;
     f.from = f.term = f.index = f.log_term = f.reject_hint = 0;
     f.reject = f.nested = false;
     f.ctx = f.ctx_len = 0;
     while (pos < end) {
-        const i64 pre = pos;
+        const typename R::pos_t pre = pos;
         u64 wire;
         if (!wire_varint(rd, pos, end, wire)) return false;
         const int32_t field = (int32_t)(u32)(wire >> 3);  // fieldNum := int32(wire >> 3)
@@ -145,17 +149,16 @@ __device__ bool wire_parse(const R& rd, i64 pos, i64 end, WireFields& f) {
                 if (wt != 2) return false;
                 u64 len;
                 if (!wire_varint(rd, pos, end, len)) return false;
-                if ((i64)len < 0) return false;           // ErrInvalidLengthRaft
-                if ((i64)len > end - pos) return false;   // io.ErrUnexpectedEOF
+                if (len > (u64)(end - pos)) return false;  // ErrInvalidLengthRaft (negative as int) / io.ErrUnexpectedEOF
                 if (field == 12) {                        // last occurrence wins (:2101)
                     f.ctx_len = len;
                     f.ctx = 0;
                     const u32 k = len < 8 ? (u32)len : 8u;
-                    for (u32 j = 0; j < k; ++j) f.ctx |= (u64)rd(pos + j) << (8 * j);
+                    for (u32 j = 0; j < k; ++j) f.ctx |= (u64)rd(pos + (typename R::pos_t)j) << (8 * j);
                 } else if (len > 0) {
                     f.nested = true;
                 }
-                pos += (i64)len;
+                pos += (typename R::pos_t)len;
                 break;
             }
             default:
@@ -164,6 +167,12 @@ __device__ bool wire_parse(const R& rd, i64 pos, i64 end, WireFields& f) {
         }
     }
     return true;
+}
+
+// A message outside the staged window (a workgroup whose 256 messages span more than the window): the same
+// parser over global memory, kept out of line so that the common path's code and registers stay small.
+__device__ __noinline__ bool wire_parse_global(const uint8_t* bytes, i64 pos, i64 end, WireFields& f) {
+    return wire_parse(GlobalBytes{bytes}, pos, end, f);
 }
 
 // The per-group lookup state of the wire path as ONE row per group, H = 3 + S
@@ -255,9 +264,11 @@ __global__ __launch_bounds__(kWireBlock) void k_ingest_wire(
             status = kWireMalformed;
         } else {
             if (window && start >= w0 && end <= w1) {
-                decoded = wire_parse(LdsBytes{sm + lead, (i64)w0}, (i64)start, (i64)end, f);
+                decoded = wire_parse(LdsBytes{sm + lead}, (u32)(start - w0), (u32)(end - w0), f);
             } else {
-                decoded = wire_parse(GlobalBytes{bytes}, (i64)start, (i64)end, f);
+                WireFields out_of_line;  // its address leaves the kernel: a copy, so that `f` itself stays in registers
+                decoded = wire_parse_global(bytes, (i64)start, (i64)end, out_of_line);
+                f = out_of_line;
             }
             if (!decoded) status = kWireMalformed;
         }
