@@ -509,7 +509,7 @@ def run_tick(raft_amd, torch, dev, local_rank, stream, reps):
                 "tick_ms": round(tick, 4), "messages_per_s": N / tick * 1e3,
                 "applied": int((d_status == 0).sum().item()), "updated": int(((d_act & 2) != 0).sum().item()),
                 "heartbeats_out": int((d_hlen != 0).sum().item()),
-                "stepper": "K9p (partition by tile, sort by cell, apply); rafthip_step_wire picks it from 2^18 events",
+                "stepper": "K9p (partition by tile, sort by cell, apply); rafthip_step_wire picks it from 2^22 events over state beyond the Infinity Cache",
                 "oracle_checked_messages": checked}
 
 

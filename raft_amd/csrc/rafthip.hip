@@ -1724,14 +1724,16 @@ static u32 prog_part_tile_shift(const rafthip_engine* e) {
     return shift;
 }
 
-// Whether a batch of n events takes the partitioned stepper (progress_part.h).  Its four passes in front of the apply
-// pass cost less per event than K9's link pass alone, so size only has to cover their fixed cost.
+// Whether a batch of n events takes the partitioned stepper (progress_part.h).  Measured (tools/step_sweep.py,
+// profiles/r03_c_step_sweep.txt): its passes have a floor of 45-70 us, and K9's random lines are cheap while the
+// Progress state (40 B per cell) stays in the 256 MiB Infinity Cache — at 2^18 groups x 9 K9 is never slower, at 2^20
+// and 2^22 groups x 9 K9p wins from 2^22 events on (1.15x ... 1.55x at 2^24).
 static bool prog_part_wanted(const rafthip_engine* e, u64 n) {
     if (e->step_mode == 1 || getenv("RAFTHIP_STEP_LINKED")) return false;
     const u32 tiles = (u32)(e->stride >> prog_part_tile_shift(e));
     if (round_up(tiles, 1u << kPartLB) > kPartMaxTiles || n > kMaxRecordsPerLaunch) return false;
     if (e->step_mode == 2) return true;
-    return n >= (1ull << 18);
+    return n >= (1ull << 22) && (u64)e->S * e->stride * (sizeof(ProgRec) + sizeof(u64)) > (256ull << 20);
 }
 
 // K9p: count, scan, two partition passes, per-tile apply; K9's link and apply kernels behind the device-side
