@@ -5,10 +5,11 @@
 // 3.5 scattered memory requests per event in the apply pass (39e9 requests/s: random 64-byte lines of HBM).
 // Here the events are first brought into tile order with K5p's two LDS-staged partition passes
 // (scatter_part.h; the records travel packed, 16 bytes with the stream index inside), and one workgroup per
-// tile of T groups then links its events through list heads in LDS and steps them: every Progress record,
-// Match cell, last index and bit-plane word it touches lies in the tile's own few runs of memory, which the
-// workgroup walks at the same time — requests that share DRAM pages, lines and TLB entries instead of
-// random ones.
+// tile of T groups then sorts its events by Progress cell and steps them in that order: the Progress
+// records, Match cells, last indexes, Inflights rings and bit-plane words a wave touches are neighbours —
+// lines shared between lanes and visited once, instead of one random line per request.  (Tile order alone is
+// not enough: with ~1000 tiles in flight their working sets do not fit the L2s, and events stepped in arrival
+// order inside a tile fetched as many lines as K9 did)
 //
 //   count    classifies every record (kMsgAppended raises the group's last index here, i.e. before every
 //            response, as K9's link pass does), writes DROPPED / DEFERRED / 0 into its action byte and
