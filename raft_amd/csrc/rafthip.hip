@@ -179,6 +179,8 @@ struct rafthip_engine {
     u64 part_cap = 0;
     u32* part_words = nullptr;  // tile counts / bases / cursors, bucket cursors, chunk table, flag
     bool part_attr = false;     // the kernels' LDS sizes have been raised on this device
+    bool part_dirty = false;    // a partitioned call did not get all its passes onto the stream: its tile counts (zero
+                                // between calls by contract) may be left behind; the next call clears the words first
     u64* d_rejected = nullptr;  // [0] acks without Progress, [1] msgs without Progress, [2] msgs of other types
     u64* h_scalar = nullptr;    // pinned, 4 x u64
     u64* d_scalar = nullptr;    // the same words as kernels address them (a total stored there needs no copy back)
@@ -1051,8 +1053,11 @@ int part_scratch(rafthip_engine* e, u64 n, PartBufs* out) {
     pb.chunk_first = pb.bucket_cursor + kPartMaxBuckets;
     pb.flag = pb.chunk_first + kPartMaxBuckets + 1;
     *out = pb;
+    if (e->part_dirty) HIP_TRY(hipMemsetAsync(e->part_words, 0, words * sizeof(u32), e->stream));
+    e->part_dirty = true;  // until the caller has put every pass on the stream (part_done)
     return RAFTHIP_OK;
 }
+void part_done(rafthip_engine* e) { e->part_dirty = false; }
 
 int scatter_partitioned(rafthip_engine* e, const Ack* d_recs, u64 n) {
     const u32 shift = part_tile_shift(e);
@@ -1092,6 +1097,7 @@ int scatter_partitioned(rafthip_engine* e, const Ack* d_recs, u64 n) {
     hipLaunchKernelGGL(k_scatter_acks_flagged, dim3((u32)(flagged_wgs < kPartFlaggedGrid ? flagged_wgs : kPartFlaggedGrid)), dim3(kBlock), 0, st, e->match, e->stride, e->G, e->S,
                        d_recs, n, static_cast<const u32*>(pb.flag));
     HIP_TRY(hipGetLastError());
+    part_done(e);
     return RAFTHIP_OK;
 }
 }  // namespace
@@ -1791,6 +1797,7 @@ static int progress_partitioned(rafthip_engine* e, const Msg* d_msgs, const u64*
                        static_cast<const u64*>(e->first_index), d_act, static_cast<const u32*>(pb.flag));
     HIP_TRY(hipGetLastError());
     e->heads_dirty = false;
+    part_done(e);
     return RAFTHIP_OK;
 }
 
