@@ -1085,12 +1085,12 @@ int scatter_partitioned(rafthip_engine* e, const Ack* d_recs, u64 n) {
                        pb.tile_count, e->d_rejected);
     hipLaunchKernelGGL(k_part_scan, dim3(1), dim3(1024), lds_count, st, pb, tiles_pad, nb);
     const u64 chunks1 = (n + kPartChunk - 1) / kPartChunk, chunks2 = chunks1 + nb;  // pass 2: an upper bound, the table has the count
-    const u32 persistent = 512;  // two workgroups per CU (64 KB of LDS each)
+    const u32 persistent = 256;  // one workgroup per CU (128 KB of LDS each)
     hipLaunchKernelGGL(k_part_partition<1>, dim3((u32)(chunks1 < persistent ? chunks1 : persistent)), dim3(kPartBlock), lds_stage, st,
                        d_recs, n, e->G, e->S, shift, nb, pb, e->part_a);
     hipLaunchKernelGGL(k_part_partition<2>, dim3((u32)(chunks2 < persistent ? chunks2 : persistent)), dim3(kPartBlock), lds_stage, st,
                        static_cast<const Ack*>(e->part_a), n, e->G, e->S, shift, nb, pb, e->part_b);
-    hipLaunchKernelGGL(k_part_apply, dim3(tiles), dim3(kPartBlock), lds_cells, st, e->match, e->stride, e->S, shift,
+    hipLaunchKernelGGL(k_part_apply, dim3(tiles), dim3(kPartApplyBlock), lds_cells, st, e->match, e->stride, e->S, shift,
                        static_cast<const Ack*>(e->part_b), pb);
     // a batch the scan found too skewed for tiles: K5's atomics on the original records (decided on the device)
     const u64 flagged_wgs = (n + kBlock - 1) / kBlock;
@@ -1774,7 +1774,7 @@ static int progress_partitioned(rafthip_engine* e, const Msg* d_msgs, const u64*
                        tiles_pad, pb.tile_count, e->term_last, d_act);
     hipLaunchKernelGGL(k_part_scan, dim3(1), dim3(1024), lds_count, st, pb, tiles_pad, nb);
     const u64 chunks1 = (n + kPartChunk - 1) / kPartChunk, chunks2 = chunks1 + nb;
-    const u32 persistent = 512;
+    const u32 persistent = 256;
     hipLaunchKernelGGL((k_part_partition<1, kPartEvents>), dim3((u32)(chunks1 < persistent ? chunks1 : persistent)), dim3(kPartBlock),
                        lds_stage1, st, reinterpret_cast<const Ack*>(d_msgs), n, e->G, e->S, shift, nb, pb, e->part_a);
     hipLaunchKernelGGL((k_part_partition<2, kPartEvents>), dim3((u32)(chunks2 < persistent ? chunks2 : persistent)), dim3(kPartBlock),

@@ -9,7 +9,7 @@
 //           into the global per-tile counts (contiguous atomics); invalid records are counted as dropped
 //   scan    one workgroup: exclusive scan -> tile bases; bucket and tile cursors; the chunk table of
 //           pass 2; the largest tile count decides whether the batch is too skewed for this form
-//   pass 1  by bucket (128 tiles).  A workgroup takes chunks of 4096 records: per-bucket ranks from LDS
+//   pass 1  by bucket (128 tiles).  A workgroup takes chunks of 8192 records: per-bucket ranks from LDS
 //           atomics, one global reservation per bucket and chunk, the records staged bucket by bucket
 //           in LDS and written out as whole runs (consecutive lanes -> consecutive addresses); the next
 //           chunk's records are already in flight while the current one is staged and written
@@ -27,8 +27,13 @@
 
 namespace rafthip {
 
-constexpr int kPartBlock = 512;        // lanes of a partition workgroup
-constexpr int kPartChunk = 4096;       // records per chunk: 64 KB of LDS staging, two workgroups per CU
+constexpr int kPartBlock = 1024;       // lanes of a partition workgroup
+constexpr int kPartApplyBlock = 512;   // lanes of a tile's workgroup in the apply pass
+// records per chunk: 128 KB of LDS staging, one 1024-lane workgroup per CU.  A chunk is cut into one run per bucket, so
+// with 128 buckets (cfg5: 16 384 tiles) 4096-record chunks gave 512-byte runs and 8192-record ones give 1 KB: the two
+// passes at 2^26 acks 515 + 562 -> together 140 us less; with 32 buckets (2^22 groups) the runs were long already and
+// nothing changes (round 3; 512 lanes x 4096 records, two workgroups per CU, before)
+constexpr int kPartChunk = 8192;
 constexpr int kPartR = kPartChunk / kPartBlock;
 constexpr u32 kPartLB = 7;             // tiles per bucket = 128
 constexpr u32 kPartMaxBuckets = 256;
@@ -185,6 +190,7 @@ __global__ __launch_bounds__(kPartBlock) void k_part_partition(const Ack* __rest
                                                                PartBufs pb, Ack* __restrict__ dst) {
     extern __shared__ ulonglong2 part_stage[];  // [kPartChunk] (+ kPartChunk digit bytes for pass 1 over events)
     __shared__ u32 hist[kPartMaxBuckets], lstart[kPartMaxBuckets + 1], gbase[kPartMaxBuckets], wsum[4];
+    static_assert(kPartMaxBuckets <= 256, "the per-bucket tables are filled by the first four waves");
     constexpr bool kPack = KIND == kPartEvents && LEVEL == 1;   // raw event records in, packed ones out
     constexpr bool kPacked = KIND == kPartEvents && LEVEL == 2;  // packed in, packed out: every record is valid
     uint8_t* const stage_dig = reinterpret_cast<uint8_t*>(part_stage + kPartChunk);  // kPack only
@@ -318,7 +324,7 @@ __global__ __launch_bounds__(kPartBlock) void k_part_partition(const Ack* __rest
 }
 
 // One workgroup per tile of T = 1 << tile_shift groups: cells[slot][group in tile] in LDS.
-__global__ __launch_bounds__(kPartBlock) void k_part_apply(u64* __restrict__ match, u64 stride, u32 S, u32 tile_shift,
+__global__ __launch_bounds__(kPartApplyBlock) void k_part_apply(u64* __restrict__ match, u64 stride, u32 S, u32 tile_shift,
                                                            const Ack* __restrict__ bins, PartBufs pb) {
     extern __shared__ u64 part_cells[];  // [S << tile_shift]
     if (pb.flag[0]) return;
@@ -327,21 +333,21 @@ __global__ __launch_bounds__(kPartBlock) void k_part_apply(u64* __restrict__ mat
     if (lo == hi) return;
     const u32 T = 1u << tile_shift, cells = S << tile_shift;
     const u64 g0 = (u64)tile << tile_shift;
-    for (u32 i = threadIdx.x * 2; i < cells; i += kPartBlock * 2) {
+    for (u32 i = threadIdx.x * 2; i < cells; i += kPartApplyBlock * 2) {
         const u32 s = i >> tile_shift, t = i & (T - 1);
         const Vec<u64, 2> v = load_stream<u64, 2>(match + (u64)s * stride + g0 + t);
         part_cells[i] = v.v[0];
         part_cells[i + 1] = v.v[1];
     }
     __syncthreads();
-    for (u32 i = lo + threadIdx.x; i < hi; i += kPartBlock) {
+    for (u32 i = lo + threadIdx.x; i < hi; i += kPartApplyBlock) {
         typedef u64 v2 __attribute__((ext_vector_type(2)));
         const v2 r = __builtin_nontemporal_load(reinterpret_cast<const v2*>(bins + i));
         const u32 group = (u32)r[0], slot = (u32)(r[0] >> 32);
         atomicMax(&part_cells[(slot << tile_shift) + (group & (T - 1))], r[1]);
     }
     __syncthreads();
-    for (u32 i = threadIdx.x * 2; i < cells; i += kPartBlock * 2) {
+    for (u32 i = threadIdx.x * 2; i < cells; i += kPartApplyBlock * 2) {
         const u32 s = i >> tile_shift, t = i & (T - 1);
         Vec<u64, 2> v;
         v.v[0] = part_cells[i];

@@ -102,7 +102,7 @@ int main(int argc, char** argv) {
     const int R = 10;
     double t[7] = {0, 0, 0, 0, 0, 0, 0};
     float ms;
-    const u32 nwg = 512, persistent = 512;
+    const u32 nwg = 512, persistent = 256;  // one 1024-lane partition workgroup per CU
     const u64 slice = (N + nwg - 1) / nwg;
     const u64 chunks1 = (N + kPartChunk - 1) / kPartChunk, chunks2 = chunks1 + nb;
     u32 flag = 0;
@@ -119,7 +119,7 @@ int main(int argc, char** argv) {
         CK(hipEventRecord(ev[4], st));
         hipLaunchKernelGGL(k_part_partition<2>, dim3((u32)(chunks2 < persistent ? chunks2 : persistent)), dim3(kPartBlock), lds_stage, st, (const Ack*)b1, N, G, S, shift, nb, pb, b2);
         CK(hipEventRecord(ev[5], st));
-        hipLaunchKernelGGL(k_part_apply, dim3(tiles), dim3(kPartBlock), lds_cells, st, m_b, G, S, shift, (const Ack*)b2, pb);
+        hipLaunchKernelGGL(k_part_apply, dim3(tiles), dim3(kPartApplyBlock), lds_cells, st, m_b, G, S, shift, (const Ack*)b2, pb);
         CK(hipEventRecord(ev[6], st));
         hipLaunchKernelGGL(k_scatter_acks_flagged, dim3((unsigned)((N + kBlock - 1) / kBlock < kPartFlaggedGrid ? (N + kBlock - 1) / kBlock : kPartFlaggedGrid)), dim3(kBlock), 0, st, m_b, G, G, S, (const Ack*)d, N, (const u32*)pb.flag);
         CK(hipEventRecord(ev[7], st));
