@@ -121,6 +121,31 @@ def test_a_batch_piled_onto_one_tile_falls_back_to_the_lists():
     random_streams(9, 4, 0, 0, "partitioned", 1000, 140000)
 
 
+@pytest.mark.parametrize("form", FORMS)
+def test_state_carries_over_many_batches(form):
+    """Twelve batches in a row on one engine, every one generated from the state the previous ones left (so acks
+    free what earlier sends put in flight, probes follow rejections, snapshots end): actions and every plane
+    against the oracle after each batch.  The partitioned form reuses its scratch — tile counts that must be zero
+    again, record buffers, the sorted runs — from batch to batch."""
+    rng = np.random.default_rng(1700)
+    S, G, cap, mb, n = 5, 100003, 4, 300, 150000
+    pl = pu.random_planes(rng, S, G, cap, mb)
+    last = pl["match"].max(axis=0) + np.uint64(64)
+    first = np.zeros(G, dtype=np.uint64)
+    active, acks = pu.mask_planes(S, G)
+    seen = np.zeros(256, dtype=np.int64)
+    with raft_amd.Engine(G, S, flags=FORMS[form]) as e:
+        upload_state(e, pl, cap, mb, active, acks, last, first)
+        for batch in range(12):
+            msgs, aux = pu.random_events(rng, n + 1000 * batch, S, G, pl, hot_cells=batch % 3 * 10)
+            act = e.step_progress(msgs, aux)
+            want = po.step_progress(pl, cap, mb, active, acks, last, first, msgs, aux)
+            assert np.array_equal(act, want), batch
+            assert_state(e, pl, active, acks, last)
+            seen += np.bincount(want, minlength=256)
+    assert seen[capi.ACT_UPDATED] > 0 and seen[capi.ACT_SEND_APPEND] > 0 and seen[capi.ACT_DEFERRED] > 0
+
+
 def random_streams(S, cap, mb, hot, form, G, n):
     rng = np.random.default_rng(1500 + S)
     pl = pu.random_planes(rng, S, G, cap, mb)
