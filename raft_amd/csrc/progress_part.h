@@ -12,8 +12,8 @@
 // order inside a tile fetched as many lines as K9 did)
 //
 //   count    classifies every record (kMsgAppended raises the group's last index here, i.e. before every
-//            response, as K9's link pass does), writes DROPPED / DEFERRED / 0 into its action byte and
-//            histograms the events by tile
+//            response, as K9's link pass does), writes DROPPED / 0 / the guessed outcome (part_action_guess)
+//            into its action byte and histograms the events by tile
 //   scan     k_part_scan
 //   pass 1   k_part_partition<1, kPartEvents>: by bucket, packing the records
 //   pass 2   k_part_partition<2, kPartEvents>: by tile
@@ -31,6 +31,15 @@
 namespace rafthip {
 
 constexpr int kProgPartBlock = 512;
+
+// The action byte the count pass writes for an event before anything is stepped: what the event most often ends
+// with in steady state — an accepted ack updates its Progress, everything else asks for nothing.  The apply pass
+// then stores an action byte only where the event's real outcome differs (and DEFERRED where an event is not
+// stepped): the byte goes to actions[stream index], one scattered store each, and at 2^24 events those stores
+// were a fifth of the pass.
+__device__ __forceinline__ uint8_t part_action_guess(u32 type, bool reject) {
+    return type == kMsgAppResp && !reject ? (uint8_t)kActUpdated : (uint8_t)0;
+}
 
 // Classify + histogram.  Grid of `count_wgs` workgroups, each over a contiguous slice.
 __global__ __launch_bounds__(kPartCountBlock) void k_prog_part_count(const Msg* __restrict__ msgs, u64 n, u64 slice, u64 G, u32 S,
@@ -55,7 +64,7 @@ __global__ __launch_bounds__(kPartCountBlock) void k_prog_part_count(const Msg* 
             act = kActDropped;
         } else {
             atomicAdd(&part_hist[group >> tile_shift], 1u);
-            act = kActDeferred;
+            act = part_action_guess(type, ((r[0] >> 48) & 0xFFu) != 0);
         }
         actions[i] = act;
     }
@@ -145,9 +154,12 @@ __global__ __launch_bounds__(kProgPartBlock) void k_prog_part_apply(const Ack* _
         const PackedEvent own = unpack_event(raw.v[0], raw.v[1], T - 1);
         const u32 c = (own.slot << tile_shift) | own.g_in_tile;
         const u32 first_pos = c ? part_cnt[c - 1] : 0;
-        if (pos != first_pos) continue;  // the first event of a cell steps all of them
         const u32 len = part_cnt[c] - first_pos;
-        if (len > kStepLimit) continue;  // all of them stay DEFERRED (the count pass wrote that)
+        if (len > kStepLimit) {  // none of them is stepped
+            actions[own.stream] = kActDeferred;
+            continue;
+        }
+        if (pos != first_pos) continue;  // the first event of a cell steps all of them
         const u64 group = g0 + own.g_in_tile;
         const u64 cell = (u64)own.slot * pl.stride + group;
         u64* rw = reinterpret_cast<u64*>(pl.rec + cell);
@@ -187,12 +199,14 @@ __global__ __launch_bounds__(kProgPartBlock) void k_prog_part_apply(const Ack* _
                 }
             }
             blocked = blocked || f.type == kEvNeedsHostRec;
+            uint8_t act = kActDeferred;
             if (!blocked) {
                 // aux: nextProbeIdx of a rejection, the bytes of a send — nothing else reads it
                 const bool wants_aux = (f.type == kMsgAppResp && f.reject) || f.type == kEvSentApp;
                 const u64 a = aux && wants_aux ? aux[f.stream] : 0;
-                actions[f.stream] = prog_step(p, pl, cell, f.type, f.reject, f.flags, f.index, a, last_index, first);
+                act = prog_step(p, pl, cell, f.type, f.reject, f.flags, f.index, a, last_index, first);
             }
+            if (act != part_action_guess(f.type, f.reject)) actions[f.stream] = act;
             done = (u64)f.stream + 1;
         }
         if (p.match != match0) pl.match[cell] = p.match;
