@@ -1,3 +1,5 @@
+# SQ / TCP / TCC counter passes (separate rocprofv3 --pmc runs) over tools/tick_bench.py for the decode, the partitioned
+# stepper's apply pass and the heartbeat emitter; prints per-kernel averages.  Usage: bash tools/pmc_tick.sh
 set -o pipefail
 export TMPDIR=/tmp
 out=gpurun_out/r3b_k8pmc
