@@ -1575,6 +1575,15 @@ struct TempPlanes {
 
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+// Groups per round of rafthip_upload_inflights / rafthip_read_inflights: the rings pass through two transient planes
+// of `rows` x groups words on the device, kept below kRingTempBytes together (a window of 256 entries over 9 slots is
+// 36 KB per group).
+constexpr size_t kRingTempBytes = 512u << 20;
+u64 ring_temp_groups(u64 rows, u64 count) {
+    const u64 fit = kRingTempBytes / (rows * 16);
+    return fit < 1 ? 1 : fit < count ? fit : count;
+}
+
 }  // namespace
 
 int rafthip_upload_progress(rafthip_engine* e, uint64_t first, uint64_t count, const uint8_t* state,
@@ -1670,18 +1679,23 @@ int rafthip_upload_inflights(rafthip_engine* e, uint64_t first, uint64_t count, 
                        e->stream, e->pp.rec, st, (u64)first, (u64)count, e->S, static_cast<const u32*>(t_meta),
                        static_cast<const u64*>(t_bytes));
     HIP_TRY(hipGetLastError());
-    // the rings: the ABI's [entry][slot][group] planes -> one contiguous ring per Progress
+    // the rings: the ABI's [entry][slot][group] planes -> one contiguous ring per Progress, through transient planes
+    // on the device, a range of groups at a time so that the transient stays below kRingTempBytes
+    const u64 step = ring_temp_groups(rows, count);
     TempPlanes tr;
-    const size_t plane_b = (size_t)rows * count * 8;
+    const size_t plane_b = (size_t)rows * step * 8;
     if ((rc = tr.alloc(2 * plane_b))) return rc;
     u64* t_ri = reinterpret_cast<u64*>(tr.base);
     u64* t_rb = reinterpret_cast<u64*>(tr.base + plane_b);
-    if ((rc = copy_rows(e, t_ri, count * 8, ring_index, src_stride * 8, count * 8, rows))) return rc;
-    if ((rc = copy_rows(e, t_rb, count * 8, ring_bytes, src_stride * 8, count * 8, rows))) return rc;
-    hipLaunchKernelGGL(k_ring_pack, dim3((u32)((count + kBlock - 1) / kBlock)), dim3(kBlock), 0, e->stream, e->pp.ring, st,
-                       (u64)first, (u64)count, e->S, e->pp.ring_len, static_cast<const u64*>(t_ri),
-                       static_cast<const u64*>(t_rb), (u64)count);
-    HIP_TRY(hipGetLastError());
+    for (u64 g0 = 0; g0 < count; g0 += step) {
+        const u64 m = count - g0 < step ? count - g0 : step;
+        if ((rc = copy_rows(e, t_ri, m * 8, ring_index + g0, src_stride * 8, m * 8, rows))) return rc;
+        if ((rc = copy_rows(e, t_rb, m * 8, ring_bytes + g0, src_stride * 8, m * 8, rows))) return rc;
+        hipLaunchKernelGGL(k_ring_pack, dim3((u32)((m + kBlock - 1) / kBlock)), dim3(kBlock), 0, e->stream, e->pp.ring, st,
+                           (u64)(first + g0), m, e->S, e->pp.ring_len, static_cast<const u64*>(t_ri),
+                           static_cast<const u64*>(t_rb), m);
+        HIP_TRY(hipGetLastError());
+    }
     HIP_TRY(hipStreamSynchronize(e->stream));
     e->stats.bytes_uploaded += count * (e->S * 12 + rows * 16);
     return RAFTHIP_OK;
@@ -1695,17 +1709,21 @@ int rafthip_read_inflights(rafthip_engine* e, uint64_t first, uint64_t count, ui
     DeviceGuard guard(e->device);
     if (count == 0 || (!ring_index && !ring_bytes)) return RAFTHIP_OK;
     const u64 st = e->stride, rows = (u64)e->pp.ring_len * e->S;
+    const u64 step = ring_temp_groups(rows, count);
     TempPlanes tr;
-    const size_t plane_b = (size_t)rows * count * 8;
+    const size_t plane_b = (size_t)rows * step * 8;
     if ((rc = tr.alloc(2 * plane_b))) return rc;
     u64* t_ri = ring_index ? reinterpret_cast<u64*>(tr.base) : nullptr;
     u64* t_rb = ring_bytes ? reinterpret_cast<u64*>(tr.base + plane_b) : nullptr;
-    hipLaunchKernelGGL(k_ring_unpack, dim3((u32)((count + kBlock - 1) / kBlock)), dim3(kBlock), 0, e->stream,
-                       static_cast<const RingEntry*>(e->pp.ring), st, (u64)first, (u64)count, e->S, e->pp.ring_len, t_ri, t_rb,
-                       (u64)count);
-    HIP_TRY(hipGetLastError());
-    if (ring_index && (rc = copy_rows(e, ring_index, dst_stride * 8, t_ri, count * 8, count * 8, rows))) return rc;
-    if (ring_bytes && (rc = copy_rows(e, ring_bytes, dst_stride * 8, t_rb, count * 8, count * 8, rows))) return rc;
+    for (u64 g0 = 0; g0 < count; g0 += step) {
+        const u64 m = count - g0 < step ? count - g0 : step;
+        hipLaunchKernelGGL(k_ring_unpack, dim3((u32)((m + kBlock - 1) / kBlock)), dim3(kBlock), 0, e->stream,
+                           static_cast<const RingEntry*>(e->pp.ring), st, (u64)(first + g0), m, e->S, e->pp.ring_len, t_ri,
+                           t_rb, m);
+        HIP_TRY(hipGetLastError());
+        if (ring_index && (rc = copy_rows(e, ring_index + g0, dst_stride * 8, t_ri, m * 8, m * 8, rows))) return rc;
+        if (ring_bytes && (rc = copy_rows(e, ring_bytes + g0, dst_stride * 8, t_rb, m * 8, m * 8, rows))) return rc;
+    }
     HIP_TRY(hipStreamSynchronize(e->stream));
     e->stats.bytes_downloaded += count * rows * ((ring_index ? 8 : 0) + (ring_bytes ? 8 : 0));
     return RAFTHIP_OK;
