@@ -59,19 +59,29 @@ struct LdsBytes {
     __device__ __forceinline__ u32 operator()(u32 pos) const { return sm[pos]; }
 };
 
-// The varint loop every field of Unmarshal uses (e.g. raft.pb.go:1807-1820):
-// at most 10 bytes, bits past 63 are shifted out, running off the buffer or an
-// 11th byte is an error.
+// The parser is written with ONE exit per loop and error flags instead of early returns: on the GPU every
+// `return false` inside nested divergent loops becomes lane-mask bookkeeping on the scalar unit, and the first form
+// of this parser (early returns throughout) spent 2200 scalar instructions per wavefront against 1100 vector ones
+// — the decode kernel ran at the scalar unit's issue rate (0.94 ms of 1.09 ms per 2^24 messages, SQ counters).
+//
+// The varint loop every field of Unmarshal uses (e.g. raft.pb.go:1807-1820): at most 10 bytes, bits past 63 are
+// shifted out; running off the buffer (io.ErrUnexpectedEOF) or an 11th byte (ErrIntOverflowRaft) is an error.
+// The loop carries ONE boolean (more) and the result (good).  Do not fold the three conditions into the `while`
+// with the last byte kept live across the exit: hipcc 7.2 built that form so that a lane whose varint ended one
+// byte before its neighbour's came out wrong (tests/test_gpu_wire.py::test_neighbouring_lanes_...).
 template <class R>
 __device__ __forceinline__ bool wire_varint(const R& rd, typename R::pos_t& pos, typename R::pos_t end, u64& v) {
     v = 0;
-    for (u32 shift = 0;; shift += 7) {
-        if (shift >= 64) return false;  // ErrIntOverflowRaft
-        if (pos >= end) return false;   // io.ErrUnexpectedEOF
+    u32 shift = 0;
+    bool good = false, more = pos < end;
+    while (more) {
         const u32 b = rd(pos++);
-        v |= (u64)(b & 0x7Fu) << shift;
-        if (b < 0x80u) return true;
+        v |= (u64)(b & 0x7Fu) << shift;  // shift <= 63 here
+        shift += 7;
+        good = b < 0x80u;
+        more = !good && shift < 70u && pos < end;
     }
+    return good;
 }
 
 // skipRaft (raft.pb.go:3027-3104) on [pos, end): skips one unknown field,
@@ -80,38 +90,37 @@ template <class R>
 __device__ bool wire_skip(const R& rd, typename R::pos_t& pos, typename R::pos_t end) {
     typename R::pos_t i = pos;
     int depth = 0;
-    while (i < end) {
-        u64 wire;
-        if (!wire_varint(rd, i, end, wire)) return false;
-        switch ((u32)wire & 7u) {
-            case 0: {
-                u64 ignored;
-                if (!wire_varint(rd, i, end, ignored)) return false;
-                break;
+    bool ok = true, done = false;
+    while (ok && !done) {
+        ok = i < end;  // io.ErrUnexpectedEOF (inside a group, after the first field)
+        u64 wire = 0;
+        ok = ok && wire_varint(rd, i, end, wire);
+        const u32 wt = (u32)wire & 7u;
+        // one arm per wire type; each leaves ok / i / depth for the common tail
+        u64 val = 0;
+        const bool has_varint = ok && (wt == 0 || wt == 2);
+        if (has_varint) ok = wire_varint(rd, i, end, val);
+        if (ok) {
+            typename R::pos_t adv = 0;
+            if (wt == 1) adv = 8;
+            if (wt == 5) adv = 4;
+            if (wt == 2) {
+                ok = val <= (u64)(end - i);  // ErrInvalidLengthRaft (negative as int) / past the end
+                adv = ok ? (typename R::pos_t)val : 0;
             }
-            case 1: i += 8; break;
-            case 2: {
-                u64 len;
-                if (!wire_varint(rd, i, end, len)) return false;
-                if (len > (u64)(end - i)) return false;  // ErrInvalidLengthRaft (negative as int) / past the end
-                i += (typename R::pos_t)len;
-                break;
-            }
-            case 3: ++depth; break;
-            case 4:
-                if (depth == 0) return false;  // ErrUnexpectedEndOfGroupRaft
+            i += adv;
+            if (wt == 3) ++depth;
+            if (wt == 4) {
+                ok = depth != 0;  // ErrUnexpectedEndOfGroupRaft
                 --depth;
-                break;
-            case 5: i += 4; break;
-            default: return false;  // illegal wireType 6, 7
+            }
+            if (wt > 5) ok = false;  // illegal wireType 6, 7
         }
-        if (i > end) return false;
-        if (depth == 0) {
-            pos = i;
-            return true;
-        }
+        ok = ok && i <= end;
+        done = ok && depth == 0;
     }
-    return false;  // io.ErrUnexpectedEOF inside a group
+    if (done) pos = i;
+    return done;
 }
 
 // Message.Unmarshal's top level.  Returns false where the reference returns an
@@ -119,54 +128,57 @@ __device__ bool wire_skip(const R& rd, typename R::pos_t& pos, typename R::pos_t
 // non-empty one sets `nested` and the message is left to the host.
 template <class R>
 __device__ bool wire_parse(const R& rd, typename R::pos_t pos, typename R::pos_t end, WireFields& f) {
+    using P = typename R::pos_t;
     f.type = 0;
     f.from = f.term = f.index = f.log_term = f.reject_hint = 0;
     f.reject = f.nested = false;
     f.ctx = f.ctx_len = 0;
-    while (pos < end) {
-        const typename R::pos_t pre = pos;
-        u64 wire;
-        if (!wire_varint(rd, pos, end, wire)) return false;
+    bool ok = true;
+    while (ok && pos < end) {
+        const P pre = pos;
+        u64 wire = 0;
+        ok = wire_varint(rd, pos, end, wire);
         const int32_t field = (int32_t)(u32)(wire >> 3);  // fieldNum := int32(wire >> 3)
         const u32 wt = (u32)wire & 7u;
-        if (wt == 4) return false;     // end group for non-group
-        if (field <= 0) return false;  // illegal tag
-        switch (field) {
-            case 1: case 2: case 3: case 4: case 5: case 6: case 8: case 10: case 11: case 13: {
-                if (wt != 0) return false;  // wrong wireType
-                u64 v;
-                if (!wire_varint(rd, pos, end, v)) return false;
-                if (field == 1) f.type = (u32)v;
-                else if (field == 3) f.from = v;
-                else if (field == 4) f.term = v;
-                else if (field == 5) f.log_term = v;
-                else if (field == 6) f.index = v;
-                else if (field == 10) f.reject = v != 0;
-                else if (field == 11) f.reject_hint = v;
-                break;
+        ok = ok && wt != 4 && field > 0;  // end group for non-group; illegal tag
+        // fields 1-6, 8, 10, 11, 13: varints; 7, 9, 12, 14: length-delimited; everything else is skipped
+        const bool scalar = field > 0 && field <= 13 && ((0x2D7Eu >> field) & 1u) != 0;
+        const bool delimited = field > 0 && field <= 14 && ((0x5280u >> field) & 1u) != 0;
+        if (ok && scalar) {
+            u64 v = 0;
+            ok = wt == 0 && wire_varint(rd, pos, end, v);  // wrong wireType
+            if (ok) {
+                f.type = field == 1 ? (u32)v : f.type;
+                f.from = field == 3 ? v : f.from;
+                f.term = field == 4 ? v : f.term;
+                f.log_term = field == 5 ? v : f.log_term;
+                f.index = field == 6 ? v : f.index;
+                f.reject = field == 10 ? v != 0 : f.reject;
+                f.reject_hint = field == 11 ? v : f.reject_hint;
             }
-            case 7: case 9: case 12: case 14: {
-                if (wt != 2) return false;
-                u64 len;
-                if (!wire_varint(rd, pos, end, len)) return false;
-                if (len > (u64)(end - pos)) return false;  // ErrInvalidLengthRaft (negative as int) / io.ErrUnexpectedEOF
-                if (field == 12) {                        // last occurrence wins (:2101)
+        } else if (ok && delimited) {
+            u64 len = 0;
+            ok = wt == 2 && wire_varint(rd, pos, end, len);
+            ok = ok && len <= (u64)(end - pos);  // ErrInvalidLengthRaft (negative as int) / io.ErrUnexpectedEOF
+            if (ok) {
+                if (field == 12) {  // last occurrence wins (:2101)
                     f.ctx_len = len;
-                    f.ctx = 0;
-                    const u32 k = len < 8 ? (u32)len : 8u;
-                    for (u32 j = 0; j < k; ++j) f.ctx |= (u64)rd(pos + (typename R::pos_t)j) << (8 * j);
+                    u64 c = 0;
+#pragma unroll
+                    for (u32 j = 0; j < 8; ++j)
+                        if ((u64)j < len) c |= (u64)rd(pos + (P)j) << (8 * j);
+                    f.ctx = c;
                 } else if (len > 0) {
                     f.nested = true;
                 }
-                pos += (typename R::pos_t)len;
-                break;
+                pos += (P)len;
             }
-            default:
-                pos = pre;
-                if (!wire_skip(rd, pos, end)) return false;
+        } else if (ok) {
+            pos = pre;
+            ok = wire_skip(rd, pos, end);
         }
     }
-    return true;
+    return ok;
 }
 
 // A message outside the staged window (a workgroup whose 256 messages span more than the window): the same
@@ -183,22 +195,33 @@ __device__ __noinline__ bool wire_parse_global(const uint8_t* bytes, i64 pos, i6
 // response type the group's campaign counts (0 = not campaigning).
 constexpr u32 kHdrTerm = 0, kHdrCtx = 1, kHdrCtxLen = 2, kHdrIds = 3;
 constexpr u32 kHdrCampaignShift = 8;
-// Rows are whole 128-byte lines: a message's lookup is a random gather, bound by the number of lines it touches,
-// and up to 13 slots a row is exactly one (96-byte rows at 32-byte alignment straddled two 128-byte lines half
-// of the time).
-__host__ __device__ __forceinline__ u32 wire_hdr_words(u32 S) { return (kHdrIds + S + 15u) & ~15u; }
+// Rows are whole aligned lines: a message's lookup is a random gather, bound by the lines and bytes it touches —
+// 64 bytes up to 5 slots (the three- and five-voter groups most hosts run), 128 bytes up to 13 slots, multiples of
+// 128 above (96-byte rows at 32-byte alignment straddled two 128-byte lines half of the time).
+__host__ __device__ __forceinline__ u32 wire_hdr_words(u32 S) { return S <= 5 ? 8u : (kHdrIds + S + 15u) & ~15u; }
 constexpr u32 kHdrLineIds = 16 - kHdrIds;  // ids in the first line of a row
 
 // The first line of a group's row, all of it requested at once (eight 16-byte loads in flight instead of a
 // chain of dependent 8-byte ones), and the slot search over it.
 struct HdrLine {
     u64 w[16];
-    __device__ __forceinline__ void load(const u64* row) {
+    __device__ __forceinline__ void load(const u64* row, u32 H) {  // H: words per row, 8 or a multiple of 16 (wave-uniform)
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < 4; ++k) {
             const Vec<u64, 2> v = load_vec<u64, 2>(row + 2 * k);
             w[2 * k] = v.v[0];
             w[2 * k + 1] = v.v[1];
+        }
+        if (H > 8) {
+#pragma unroll
+            for (int k = 4; k < 8; ++k) {
+                const Vec<u64, 2> v = load_vec<u64, 2>(row + 2 * k);
+                w[2 * k] = v.v[0];
+                w[2 * k + 1] = v.v[1];
+            }
+        } else {
+#pragma unroll
+            for (int k = 8; k < 16; ++k) w[k] = 0;  // never an id: find() stops at S <= 5
         }
     }
     // the first slot whose id is `from` (r.trk.Progress[m.From]); ids beyond the first line are read from the row
@@ -291,7 +314,7 @@ __global__ __launch_bounds__(kWireBlock) void k_ingest_wire(
                 // slower (1172 -> 1239 us per 2^24 messages; the kernel is bound by what it moves, not by latency)
                 const u64* row = hdr + (u64)group * H;  // one line holds all the group's lookup state (S <= 13)
                 HdrLine line;
-                line.load(row);
+                line.load(row, H);
                 const u64 term = line.w[kHdrTerm];
                 // raft.go:1068-1076: a granted MsgPreVoteResp carries the pre-candidate's future term and does
                 // not make it a follower

@@ -112,6 +112,33 @@ def test_ingest_wire_long_messages_leave_the_lds_window(oracle):
         assert counts[capi.WIRE_APPLIED] > n // 2
 
 
+def test_neighbouring_lanes_on_different_paths_of_the_parser(oracle):
+    """Lanes of one wavefront parse different messages in lockstep: every pair of tails — unknown fields of every wire
+    type behind one- and two-byte tags, varints of every length, a context, truncations — side by side in both orders
+    (a form of the varint loop once decoded a one-byte tag wrongly when its neighbour's tag took two bytes)."""
+    rng = np.random.default_rng(1450)
+    S, G = 3, 16
+    state = make_state(rng, S, G)
+    ids, term = state[0], state[1]
+    g = int(np.flatnonzero((ids != 0).all(axis=0))[0]) if (ids != 0).all(axis=0).any() else 0
+    frm = int(ids[0, g]) if ids[0, g] else 1
+    base = wu.encode_message(type=wu.MSG_APP_RESP, frm=frm, term=int(term[g]), index=77)
+    tails = [b"", wu.tag(15, 0) + wu.varint(1), wu.tag(15, 0) + wu.varint((1 << 63) + 5), wu.tag(31, 5) + bytes(4),
+             wu.tag(31, 1) + bytes(8), wu.tag(99, 2) + wu.varint(3) + b"abc", wu.tag(200, 0) + wu.varint(300),
+             wu.tag(17, 3) + wu.tag(18, 0) + wu.varint(9) + wu.tag(17, 4), wu.tag(12, 2) + wu.varint(2) + b"hi",
+             wu.tag(15, 0) + b"\x80", wu.tag(31, 5) + bytes(2), wu.tag(16, 4), wu.tag(3000, 0) + wu.varint(1 << 40),
+             wu.tag(15, 0) + b"\x80" * 10 + b"\x01"]
+    blobs, groups = [], []
+    for a in tails:
+        for b in tails:
+            blobs += [base + a, base + b]
+    data, offsets = wu.pack(blobs)
+    groups = np.full(len(blobs), g, dtype=np.uint32)
+    with raft_amd.Engine(G, S) as e:
+        counts = run_both(oracle, e, state, data, offsets, groups)
+        assert counts[capi.WIRE_APPLIED] > 0 and counts[capi.WIRE_MALFORMED] > 0
+
+
 def test_ingest_wire_bad_offsets_and_empty(oracle):
     rng = np.random.default_rng(1400)
     S, G = 4, 8

@@ -28,8 +28,10 @@ def main():
     import wire_util as wu
 
     sh = int(sys.argv[1]) if len(sys.argv) > 1 else 0
-    G, S, V, cap = (1 << 22) >> sh, 9, 7, 4
+    S = int(os.environ.get("TICK_SLOTS", "9"))  # 9 = 7 voters + 2 learners (cfg5); 5 = five voters, 3 = three
+    G, V, cap = (1 << 22) >> sh, {9: 7}.get(S, S), 4
     N = 4 * G
+    mdt = np.uint8 if S <= 8 else np.uint16  # slot masks: one byte up to 8 slots
     dev = torch.device("cuda", 0)
     stream = torch.cuda.Stream(device=dev)
     rng = np.random.default_rng(0x5EED0009)
@@ -61,7 +63,7 @@ def main():
         e.upload_ids(ids)
         e.upload_term(term)
         e.upload_read_ctx(ctx, np.full(G, 8, dtype=np.uint8))
-        e.upload_self(np.ones(G, dtype=np.uint16))
+        e.upload_self(np.ones(G, dtype=mdt))
 
         def reset():
             e.upload_match(pl["match"])
@@ -70,8 +72,8 @@ def main():
                 e.upload_inflights(pl["infl_meta"], pl["infl_bytes"], pl["ring_index"], pl["ring_bytes"])
             e.upload_commit(np.zeros(G, dtype=np.uint64))
             e.upload_term_range(np.zeros(G, dtype=np.uint64), last)
-            e.upload_active(np.ones(G, dtype=np.uint16))
-            e.upload_acks(np.zeros(G, dtype=np.uint16))
+            e.upload_active(np.ones(G, dtype=mdt))
+            e.upload_acks(np.zeros(G, dtype=mdt))
 
         stages = [
             ("step_wire", lambda: L.rafthip_step_wire(e._h, d_data.data_ptr(), d_off.data_ptr(), d_grp.data_ptr(), N, None,
@@ -101,8 +103,8 @@ def main():
         plane = np.zeros((S, G), dtype=np.uint64)
         np.maximum.at(plane, (slots, groups), pl["match"][slots, groups] + rng.integers(2, 64, size=N).astype(np.uint64))
         d_plane = torch.from_numpy(plane.view(np.int64)).to(dev)
-        hbm = rng.integers(0, 1 << S, size=G).astype(np.uint16)
-        d_hb = torch.from_numpy(hbm.view(np.int16)).to(dev)
+        hbm = rng.integers(0, 1 << S, size=G).astype(mdt)
+        d_hb = torch.from_numpy(hbm.view(np.int8 if S <= 8 else np.int16)).to(dev)
         d_dact = torch.zeros((S, G), dtype=torch.uint8, device=dev)
         dense_events = int(np.count_nonzero(plane)) + int(np.unpackbits(hbm.view(np.uint8)).sum())
         stages_d = [("step_dense", lambda: L.rafthip_step_dense(e._h, 0, G, d_plane.data_ptr(), G, d_hb.data_ptr(), None,
