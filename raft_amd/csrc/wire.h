@@ -72,8 +72,14 @@ struct LdsBytes {
 template <class R>
 __device__ __forceinline__ bool wire_varint(const R& rd, typename R::pos_t& pos, typename R::pos_t end, u64& v) {
     v = 0;
-    u32 shift = 0;
-    bool good = false, more = pos < end;
+    u32 shift = 7;
+    bool good = false, more = false;
+    if (pos < end) {  // the first byte outside the loop: tags and most small values end here
+        const u32 b = rd(pos++);
+        v = b & 0x7Fu;
+        good = b < 0x80u;
+        more = !good && pos < end;
+    }
     while (more) {
         const u32 b = rd(pos++);
         v |= (u64)(b & 0x7Fu) << shift;  // shift <= 63 here
