@@ -918,6 +918,15 @@ __global__ __launch_bounds__(kBlock) void k_pack_changed(const u64* __restrict__
 }
 
 // The same for the shards of rafthip_commit_report_many (K1 tiles): one launch, every shard packed into its own buffer.
+// The first min(*total, limit) packed pairs once more, into the engine's page-locked arena: a report of few pairs
+// reaches a pageable destination without a second copy-and-wait (rafthip.hip commit_report).
+__global__ __launch_bounds__(kBlock) void k_copy_head(const Pair* __restrict__ packed, const u64* __restrict__ total,
+                                                      u32 limit, Pair* __restrict__ head) {
+    const u64 t = *total;
+    const u32 m = t < limit ? (u32)t : limit;
+    for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) head[i] = packed[i];
+}
+
 struct ManyPack {
     u32 n;
     u32 first_tile[kManyMax + 1];

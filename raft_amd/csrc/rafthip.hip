@@ -68,6 +68,9 @@ int fail(int code, const char* fmt, ...) {
 u64 round_up(u64 x, u64 a) { return (x + a - 1) / a * a; }
 
 constexpr u64 kMaxRecordsPerLaunch = 1ull << 30;  // scatter / ingest records per kernel launch
+constexpr size_t kSmallArenaBytes = 4u << 20;     // rafthip_engine::h_small
+constexpr u64 kSmallPairs = 4096;                 // (group, commit) pairs of a report that come back through it
+constexpr u64 kSmallBatch = 32768;                // messages per call up to which the wire entry points use it
 
 int mask_bytes_for(u32 S) { return S <= 8 ? 1 : S <= 16 ? 2 : S <= 32 ? 4 : 8; }
 
@@ -182,6 +185,13 @@ struct rafthip_engine {
     bool part_dirty = false;    // a partitioned call did not get all its passes onto the stream: its tile counts (zero
                                 // between calls by contract) may be left behind; the next call clears the words first
     u64* d_rejected = nullptr;  // [0] acks without Progress, [1] msgs without Progress, [2] msgs of other types
+    // Small batches from / to pageable host memory (the wire entry points): inputs are copied by the CPU into this
+    // page-locked, device-mapped arena and read from there by the kernels, outputs are written into it by the kernels
+    // and copied out by the CPU after the call's one wait — no DMA copies, each of which costs ~10 us whatever its
+    // size.  Bump-allocated per call; a call that uses it waits for the stream before it returns.
+    char* h_small = nullptr;
+    char* d_small = nullptr;    // the same memory as the device sees it
+    size_t small_used = 0;
     u64* h_scalar = nullptr;    // pinned, 4 x u64
     u64* d_scalar = nullptr;    // the same words as kernels address them (a total stored there needs no copy back)
 
@@ -593,6 +603,16 @@ Pair* device_addressable(void* dst) {
 
 // Commit pass that reports pairs (MODE kChanged / kAdvance): the reporting pass,
 // then the total and — for a pageable dst — the pairs come back.
+// `bytes` of the engine's small arena (rafthip_engine::h_small), 256-byte aligned: host view, device view; NULL when
+// the call has used it up.
+char* small_take(rafthip_engine* e, size_t bytes, char** dev) {
+    const size_t at = (e->small_used + 255) & ~(size_t)255;
+    if (!e->h_small || at + bytes > kSmallArenaBytes) return nullptr;
+    e->small_used = at + bytes;
+    *dev = e->d_small + at;
+    return e->h_small + at;
+}
+
 template <int MODE>
 static int commit_report(rafthip_engine* e, rafthip_commit_pair* dst, uint64_t max_pairs, uint64_t* n_out) {
     if (!e || !n_out) return fail(RAFTHIP_EINVAL, "engine/count pointer is NULL");
@@ -614,11 +634,25 @@ static int commit_report(rafthip_engine* e, rafthip_commit_pair* dst, uint64_t m
         cap = max_pairs < e->G ? max_pairs : e->G;
     }
     if ((rc = report_pass<MODE>(e, rb, 0, d_out, cap, e->d_scalar + 1))) return rc;  // the total lands in h_scalar[1]
+    const Pair* head = nullptr;  // a short report, in the page-locked arena by the time the wait returns
+    if (landing) {
+        e->small_used = 0;
+        char* d = nullptr;
+        const u32 limit = cap < kSmallPairs ? (u32)cap : (u32)kSmallPairs;
+        if (char* h = small_take(e, (size_t)limit * sizeof(Pair), &d)) {
+            hipLaunchKernelGGL(k_copy_head, dim3((limit + kBlock - 1) / kBlock), dim3(kBlock), 0, e->stream, e->packed,
+                               e->d_scalar + 1, limit, reinterpret_cast<Pair*>(d));
+            HIP_TRY(hipGetLastError());
+            head = reinterpret_cast<const Pair*>(h);
+        }
+    }
     HIP_TRY(hipStreamSynchronize(e->stream));
     const u64 total = e->h_scalar[1];
     *n_out = total;
     const u64 ncopy = total < max_pairs ? total : max_pairs;
-    if (landing && ncopy) {
+    if (landing && ncopy && head && ncopy <= kSmallPairs) {
+        memcpy(dst, head, ncopy * sizeof(Pair));
+    } else if (landing && ncopy) {
         HIP_TRY(hipMemcpyAsync(dst, e->packed, ncopy * sizeof(Pair), hipMemcpyDeviceToHost, e->stream));
         HIP_TRY(hipStreamSynchronize(e->stream));
     }
@@ -652,8 +686,9 @@ int stage_reserve(rafthip_engine* e, StageSlot k, size_t bytes) {
     return RAFTHIP_OK;
 }
 
-// Input k as a device-visible pointer: device memory and page-locked host memory as they are, pageable host memory copied in.
-int stage_input(rafthip_engine* e, StageSlot k, const void* src, size_t bytes, const void** dev) {
+// Input k as a device-visible pointer: device memory and page-locked host memory as they are, pageable host memory copied in
+// (`small`: through the arena when it fits, see rafthip_engine::h_small).
+int stage_input(rafthip_engine* e, StageSlot k, const void* src, size_t bytes, const void** dev, bool small = false) {
     if (bytes == 0) {
         *dev = src;
         return RAFTHIP_OK;
@@ -672,6 +707,15 @@ int stage_input(rafthip_engine* e, StageSlot k, const void* src, size_t bytes, c
         }
     }
     (void)hipGetLastError();
+    if (small) {
+        char* d = nullptr;
+        if (char* h = small_take(e, bytes, &d)) {
+            memcpy(h, src, bytes);
+            e->stats.bytes_uploaded += bytes;
+            *dev = d;
+            return RAFTHIP_OK;
+        }
+    }
     int rc = stage_reserve(e, k, bytes);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(e->stage_buf[k], src, bytes, hipMemcpyHostToDevice, e->stream));
@@ -768,6 +812,13 @@ int rafthip_create(const rafthip_config* cfg, rafthip_engine** out) {
             rc = fail(RAFTHIP_ENOMEM, "hipHostMalloc: %s", hipGetErrorString(err));
             break;
         }
+        err = hipHostMalloc(reinterpret_cast<void**>(&e->h_small), kSmallArenaBytes,
+                            hipHostMallocMapped | hipHostMallocCoherent);
+        if (err == hipSuccess) err = hipHostGetDevicePointer(reinterpret_cast<void**>(&e->d_small), e->h_small, 0);
+        if (err != hipSuccess) {
+            rc = fail(RAFTHIP_ENOMEM, "hipHostMalloc: %s", hipGetErrorString(err));
+            break;
+        }
         err = hipStreamSynchronize(e->stream);
         if (err != hipSuccess) rc = fail(RAFTHIP_EIO, "hipStreamSynchronize: %s", hipGetErrorString(err));
     } while (0);
@@ -797,6 +848,7 @@ int rafthip_destroy(rafthip_engine* e) {
     for (void* b : e->stage_buf)
         if (b) (void)hipFree(b);
     if (e->h_scalar) (void)hipHostFree(e->h_scalar);
+    if (e->h_small) (void)hipHostFree(e->h_small);
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
     return RAFTHIP_OK;
@@ -1397,6 +1449,12 @@ static int wire_run(rafthip_engine* e, const uint8_t* bytes, const uint64_t* off
     if ((rc = ensure(e, e->acks, mb))) return rc;
     if ((rc = ensure(e, e->d_wire_counts, RAFTHIP_WIRE_STATUSES * sizeof(u64)))) return rc;
 
+    // a small batch from / to pageable host memory goes through the page-locked arena, not through DMA copies
+    const bool small = n <= kSmallBatch;
+    e->small_used = 0;
+    struct { void* dst; const void* src; size_t bytes; } after[5];  // arena -> caller, once the stream has drained
+    int n_after = 0;
+
     // total byte length = offsets[n] (the kernel bounds every message by it)
     const void* d_off = nullptr;
     u64 nbytes = 0;
@@ -1407,17 +1465,37 @@ static int wire_run(rafthip_engine* e, const uint8_t* bytes, const uint64_t* off
         d_off = offsets;
     } else {
         nbytes = offsets[n];
-        if ((rc = stage_input(e, kStageOffsets, offsets, (size_t)(n + 1) * sizeof(u64), &d_off))) return rc;
+        if ((rc = stage_input(e, kStageOffsets, offsets, (size_t)(n + 1) * sizeof(u64), &d_off, small))) return rc;
     }
     if (nbytes > 0 && !bytes) return fail(RAFTHIP_EINVAL, "bytes is NULL");
     const void *d_bytes = nullptr, *d_groups = nullptr;
-    if ((rc = stage_input(e, kStageBytes, bytes, (size_t)nbytes, &d_bytes))) return rc;
-    if ((rc = stage_input(e, kStageGroups, groups, (size_t)n * sizeof(u32), &d_groups))) return rc;
+    if ((rc = stage_input(e, kStageBytes, bytes, (size_t)nbytes, &d_bytes, small))) return rc;
+    if ((rc = stage_input(e, kStageGroups, groups, (size_t)n * sizeof(u32), &d_groups, small))) return rc;
     Msg* d_msgs = nullptr;
     uint8_t* d_status = nullptr;
-    const bool msgs_host = out_msgs && !is_device_ptr(out_msgs);
-    const bool status_host = out_status && !is_device_ptr(out_status);
-    if (out_msgs && !msgs_host) {
+    bool msgs_host = out_msgs && !is_device_ptr(out_msgs);
+    bool status_host = out_status && !is_device_ptr(out_status);
+    // an output the kernels only write can live in the arena; the messages are read back by the passes that follow the
+    // decode (Progress, votes), so those calls keep them in device memory
+    auto small_output = [&](void* dst, size_t bytes) -> char* {
+        char* d = nullptr;
+        char* h = small ? small_take(e, bytes, &d) : nullptr;
+        if (!h) return nullptr;
+        after[n_after].dst = dst;
+        after[n_after].src = h;
+        after[n_after].bytes = bytes;
+        ++n_after;
+        e->stats.bytes_downloaded += bytes;
+        return d;
+    };
+    if (msgs_host && !to_progress && !e->campaigning) {
+        if (char* d = small_output(out_msgs, (size_t)n * sizeof(Msg))) {
+            d_msgs = reinterpret_cast<Msg*>(d);
+            msgs_host = false;
+        }
+    }
+    if (d_msgs) {
+    } else if (out_msgs && !msgs_host) {
         d_msgs = reinterpret_cast<Msg*>(out_msgs);
     } else if (out_msgs || to_progress || e->campaigning) {
         if ((rc = stage_reserve(e, kStageMsgs, (size_t)n * sizeof(Msg)))) return rc;
@@ -1428,7 +1506,13 @@ static int wire_run(rafthip_engine* e, const uint8_t* bytes, const uint64_t* off
         if ((rc = stage_reserve(e, kStageAux, (size_t)n * sizeof(u64)))) return rc;
         d_aux = static_cast<u64*>(e->stage_buf[kStageAux]);
     }
-    if (out_status) {
+    if (status_host) {
+        if (char* d = small_output(out_status, (size_t)n)) {
+            d_status = reinterpret_cast<uint8_t*>(d);
+            status_host = false;
+        }
+    }
+    if (out_status && !d_status) {
         if (status_host) {
             if ((rc = stage_reserve(e, kStageStatus, (size_t)n))) return rc;
             d_status = static_cast<uint8_t*>(e->stage_buf[kStageStatus]);
@@ -1436,10 +1520,16 @@ static int wire_run(rafthip_engine* e, const uint8_t* bytes, const uint64_t* off
             d_status = out_status;
         }
     }
-    const bool act_host = to_progress && (!actions || !is_device_ptr(actions));
+    bool act_host = to_progress && (!actions || !is_device_ptr(actions));
     uint8_t* d_act = actions;
     u32* d_prev = nullptr;
     if (to_progress) {  // the decode kernel also links each event into its Progress's list (k_progress_link's work)
+        if (act_host && actions) {
+            if (char* d = small_output(actions, (size_t)n)) {
+                d_act = reinterpret_cast<uint8_t*>(d);
+                act_host = false;
+            }
+        }
         if (act_host) {
             if ((rc = stage_reserve(e, kStageActions, (size_t)n))) return rc;
             d_act = static_cast<uint8_t*>(e->stage_buf[kStageActions]);
@@ -1478,29 +1568,40 @@ static int wire_run(rafthip_engine* e, const uint8_t* bytes, const uint64_t* off
                            e->stride, e->G, e->S, d_msgs, (u32)n, no_count);
         HIP_TRY(hipGetLastError());
     }
-    bool wait = d_bytes != bytes || d_off != offsets || d_groups != groups || e->zero_copy_pending;  // caller may reuse its host buffers
+    bool wait = d_bytes != bytes || d_off != offsets || d_groups != groups || e->zero_copy_pending || n_after;  // caller may reuse its host buffers
     e->zero_copy_pending = false;
-    if (msgs_host) {
-        HIP_TRY(hipMemcpyAsync(out_msgs, d_msgs, (size_t)n * sizeof(Msg), hipMemcpyDeviceToHost, e->stream));
-        e->stats.bytes_downloaded += n * sizeof(Msg);
+    // what is left in device memory comes back through the arena too when it fits: a copy into page-locked memory is
+    // one asynchronous transfer, a copy into pageable memory is staged and waited for by the runtime piece by piece
+    auto download = [&](void* dst, const void* src, size_t bytes) -> hipError_t {
+        char* d = nullptr;
+        char* h = small ? small_take(e, bytes, &d) : nullptr;
+        if (h && n_after < (int)(sizeof(after) / sizeof(after[0]))) {
+            after[n_after].dst = dst;
+            after[n_after].src = h;
+            after[n_after].bytes = bytes;
+            ++n_after;
+            dst = h;
+        }
         wait = true;
+        return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, e->stream);
+    };
+    if (msgs_host) {
+        HIP_TRY(download(out_msgs, d_msgs, (size_t)n * sizeof(Msg)));
+        e->stats.bytes_downloaded += n * sizeof(Msg);
     }
     if (status_host) {
         HIP_TRY(hipMemcpyAsync(out_status, d_status, (size_t)n, hipMemcpyDeviceToHost, e->stream));
         e->stats.bytes_downloaded += n;
         wait = true;
     }
-    if (status_counts) {
-        HIP_TRY(hipMemcpyAsync(status_counts, e->d_wire_counts, RAFTHIP_WIRE_STATUSES * sizeof(u64),
-                               hipMemcpyDeviceToHost, e->stream));
-        wait = true;
-    }
+    if (status_counts) HIP_TRY(download(status_counts, e->d_wire_counts, RAFTHIP_WIRE_STATUSES * sizeof(u64)));
     if (to_progress && actions && act_host) {
         HIP_TRY(hipMemcpyAsync(actions, d_act, (size_t)n, hipMemcpyDeviceToHost, e->stream));
         e->stats.bytes_downloaded += n;
         wait = true;
     }
     if (wait) HIP_TRY(hipStreamSynchronize(e->stream));
+    for (int i = 0; i < n_after; ++i) memcpy(after[i].dst, after[i].src, after[i].bytes);
     e->stats.msgs_ingested += n;
     return RAFTHIP_OK;
 }

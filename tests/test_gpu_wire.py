@@ -275,6 +275,60 @@ def test_step_wire_feeds_the_progress_stepper(oracle, S, cap, form):
         assert np.array_equal(e.read_progress()["next"], pl["next"])
 
 
+def test_small_batches_from_host_memory_either_side_of_the_arena(oracle):
+    """Batches of up to 32768 messages from pageable host memory go through the engine's page-locked arena
+    (rafthip.hip small_take) instead of DMA copies, piece by piece as each fits: the same answers either side of the
+    message limit, with a payload larger than the arena, and call after call on one engine."""
+    import progress_util as pu
+    from oracle import pyoracle as po
+    rng = np.random.default_rng(1900)
+    S, G, cap = 5, 3001, 4
+    ids, term, ctxs, _, _, _ = make_state(rng, S, G)
+    cw, cl = wu.ctx_words(ctxs)
+    pl = pu.random_planes(rng, S, G, cap, 0)
+    last = pl["match"].max(axis=0) + np.uint64(1 << 20)
+    first = np.zeros(G, dtype=np.uint64)
+    active, acks = pu.mask_planes(S, G)
+    with raft_amd.Engine(G, S) as e:
+        e.progress_config(cap, 0)
+        e.upload_match(pl["match"])
+        e.upload_progress(pl["pstate"], pl["next"], pl["pending"])
+        e.upload_inflights(pl["infl_meta"], pl["infl_bytes"], pl["ring_index"], pl["ring_bytes"])
+        e.upload_active(active)
+        e.upload_acks(acks)
+        e.upload_term_range(np.zeros(G, dtype=np.uint64), last)
+        e.upload_first_index(first)
+        e.upload_ids(ids)
+        e.upload_term(term)
+        e.upload_read_ctx(cw, cl)
+        for n, fat in [(32769, 0), (32768, 0), (1, 0), (100, 0), (3000, 5), (100, 0), (9000, 0), (1200, 3)]:
+            blobs, groups = wu.random_batch(rng, n, G, ids, term, ctxs, bad_frac=0.1)
+            for i in range(0, n, fat or n + 1):  # fat > 0: unknown fields that push the payload past the arena's 4 MiB
+                if fat:
+                    pad = bytes(rng.integers(0, 256, size=int(rng.integers(9000, 15000)), dtype=np.uint8))
+                    blobs[i] = wu.tag(99, 2) + wu.varint(len(pad)) + pad + blobs[i]
+            data, offsets = wu.pack(blobs)
+            assert (len(data) > (4 << 20)) == bool(fat)
+            want_msgs, want_aux, want_status, want_counts = oracle.decode_wire_msgs(ids, term, cw, cl, data, offsets,
+                                                                                    groups)
+            msgs, status, counts, act = e.step_wire(data, offsets, groups)
+            assert np.array_equal(status, want_status) and np.array_equal(counts, want_counts)
+            assert np.array_equal(msgs, want_msgs)
+            want_act = po.step_progress(pl, cap, 0, active, acks, last, first, want_msgs, want_aux)
+            assert np.array_equal(act, want_act)
+            assert np.array_equal(e.read_match(), pl["match"])
+            assert np.array_equal(e.read_progress()["next"], pl["next"])
+            # the decode alone (messages through the arena as well), on a copy of the state
+            wm, wa, wk = pl["match"].copy(), active.copy(), acks.copy()
+            m2, s2, c2 = oracle.step_wire_msgs(wm, wa, wk, ids, term, cw, cl, data, offsets, groups)
+            msgs, status, counts = e.ingest_wire(data, offsets, groups)
+            assert np.array_equal(msgs, m2) and np.array_equal(status, s2) and np.array_equal(counts, c2)
+            assert np.array_equal(e.read_match(), wm)
+            pl["match"][:] = wm
+            active[:], acks[:] = wa, wk
+            assert np.array_equal(e.read_active(), active) and np.array_equal(e.read_acks(), acks)
+
+
 class EngineVoteDriver:
     """tests/golden/scenarios.json's wire_vote_sequences on the engine: the scenario's group sits among G others."""
 
