@@ -549,6 +549,17 @@ static int oneshot_engine(int device, uint64_t G, uint32_t S, const void* in_mas
     return RAFTHIP_OK;
 }
 
+// `bytes` of the engine's small arena (rafthip_engine::h_small), 256-byte aligned: host view, device view; NULL when
+// the call has used it up.
+char* small_take(rafthip_engine* e, size_t bytes, char** dev) {
+    static const bool off = getenv("RAFTHIP_NO_SMALL_ARENA") != nullptr;  // A/B switch for tools/small_tick_probe.py
+    const size_t at = (e->small_used + 255) & ~(size_t)255;
+    if (off || !e->h_small || at + bytes > kSmallArenaBytes) return nullptr;
+    e->small_used = at + bytes;
+    *dev = e->d_small + at;
+    return e->h_small + at;
+}
+
 // 16-byte records (acks or msgs) -> a device pointer; host memory is staged
 // through the engine's record buffer.
 static int stage_records(rafthip_engine* e, const void* recs, uint64_t n, const void** d_recs, bool* staged) {
@@ -570,6 +581,17 @@ static int stage_records(rafthip_engine* e, const void* recs, uint64_t n, const 
         }
     }
     (void)hipGetLastError();  // plain host memory reports an error on some runtimes
+    if (n <= kSmallBatch) {   // a small batch: through the page-locked arena, no DMA copy (every caller waits when staged)
+        e->small_used = 0;
+        char* d = nullptr;
+        if (char* h = small_take(e, n * sizeof(Ack), &d)) {
+            memcpy(h, recs, n * sizeof(Ack));
+            *d_recs = d;
+            *staged = true;
+            e->stats.bytes_uploaded += n * sizeof(Ack);
+            return RAFTHIP_OK;
+        }
+    }
     if (e->ack_cap < n) {
         if (e->ack_buf) {
             HIP_TRY(hipStreamSynchronize(e->stream));
@@ -603,16 +625,6 @@ Pair* device_addressable(void* dst) {
 
 // Commit pass that reports pairs (MODE kChanged / kAdvance): the reporting pass,
 // then the total and — for a pageable dst — the pairs come back.
-// `bytes` of the engine's small arena (rafthip_engine::h_small), 256-byte aligned: host view, device view; NULL when
-// the call has used it up.
-char* small_take(rafthip_engine* e, size_t bytes, char** dev) {
-    const size_t at = (e->small_used + 255) & ~(size_t)255;
-    if (!e->h_small || at + bytes > kSmallArenaBytes) return nullptr;
-    e->small_used = at + bytes;
-    *dev = e->d_small + at;
-    return e->h_small + at;
-}
-
 template <int MODE>
 static int commit_report(rafthip_engine* e, rafthip_commit_pair* dst, uint64_t max_pairs, uint64_t* n_out) {
     if (!e || !n_out) return fail(RAFTHIP_EINVAL, "engine/count pointer is NULL");
@@ -2097,11 +2109,21 @@ int rafthip_step_progress(rafthip_engine* e, const rafthip_msg* msgs, const uint
     if ((rc = ensure(e, e->acks, mb))) return rc;
     const void* d_recs = nullptr;
     bool staged = false;
+    e->small_used = 0;
     if ((rc = stage_records(e, msgs, n, &d_recs, &staged))) return rc;
     const void* d_aux = nullptr;
-    if (aux && (rc = stage_input(e, kStageAux, aux, (size_t)n * sizeof(u64), &d_aux))) return rc;
-    const bool act_host = !actions || !is_device_ptr(actions);
+    const bool small = staged && !is_device_ptr(d_recs) && n <= kSmallBatch;  // stage_records took the arena
+    if (aux && (rc = stage_input(e, kStageAux, aux, (size_t)n * sizeof(u64), &d_aux, small))) return rc;
+    bool act_host = !actions || !is_device_ptr(actions);
     uint8_t* d_act = actions;
+    const char* h_act = nullptr;
+    if (act_host && actions && small) {
+        char* d = nullptr;
+        if ((h_act = small_take(e, (size_t)n, &d))) {
+            d_act = reinterpret_cast<uint8_t*>(d);
+            act_host = false;
+        }
+    }
     if (act_host) {
         if ((rc = stage_reserve(e, kStageActions, (size_t)n))) return rc;
         d_act = static_cast<uint8_t*>(e->stage_buf[kStageActions]);
@@ -2117,6 +2139,10 @@ int rafthip_step_progress(rafthip_engine* e, const rafthip_msg* msgs, const uint
         wait = true;
     }
     if (wait) HIP_TRY(hipStreamSynchronize(e->stream));
+    if (h_act) {
+        memcpy(actions, h_act, (size_t)n);
+        e->stats.bytes_downloaded += n;
+    }
     e->stats.msgs_ingested += n;
     return RAFTHIP_OK;
 }

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Latency of a SMALL leader tick through the C ABI, host buffers in and out (what a host with a light load sees):
 n serialized responses -> rafthip_step_wire (status + action bytes back) -> rafthip_commit_advance (advanced pairs
-back).  2^20 groups x 5 slots; wall-clock microseconds per call, median of 200."""
+back); the same acks as records -> rafthip_scatter_acks, and as decoded messages -> rafthip_step_progress.
+2^20 groups x 5 slots; wall-clock microseconds per call, median of 200.  RAFTHIP_NO_SMALL_ARENA=1 in the environment:
+every pageable buffer through its own DMA copy, the form before round 3's arena."""
 import json
 import os
 import sys
@@ -18,6 +20,7 @@ def main():
     import progress_util as pu
     import raft_amd
     import wire_util as wu
+    from raft_amd import capi
 
     G, S, cap = 1 << 20, 5, 4
     rng = np.random.default_rng(0x5EED000B)
@@ -40,7 +43,7 @@ def main():
         e.upload_active(np.ones(G, dtype=np.uint8))
         bump = 0
         for n in (100, 1000, 10000, 30000, 100000, 200000):
-            ts_step, ts_commit = [], []
+            ts_step, ts_commit, ts_scatter, ts_prog = [], [], [], []
             for it in range(220):
                 groups = rng.integers(0, G, size=n).astype(np.uint32)
                 slots = rng.integers(0, S, size=n)
@@ -52,11 +55,26 @@ def main():
                 t1 = time.perf_counter()
                 e.commit_advance()
                 t2 = time.perf_counter()
+                acks = np.zeros(n, dtype=capi.ACK_DTYPE)
+                acks["group"], acks["slot"] = groups, slots
+                acks["index"] = pl["match"][slots, groups] + np.uint64(bump)
+                msgs = np.zeros(n, dtype=capi.MSG_DTYPE)
+                msgs["group"], msgs["slot"], msgs["type"] = groups, slots, capi.MSG_APP_RESP
+                msgs["index"] = acks["index"] + np.uint64(1)
+                t3 = time.perf_counter()
+                e.scatter_acks(acks)
+                t4 = time.perf_counter()
+                e.step_progress(msgs)
+                t5 = time.perf_counter()
                 if it >= 20:
                     ts_step.append(t1 - t0)
                     ts_commit.append(t2 - t1)
+                    ts_scatter.append(t4 - t3)
+                    ts_prog.append(t5 - t4)
             out[str(n)] = {"step_wire_us": round(1e6 * float(np.median(ts_step)), 1),
-                           "commit_advance_us": round(1e6 * float(np.median(ts_commit)), 1)}
+                           "commit_advance_us": round(1e6 * float(np.median(ts_commit)), 1),
+                           "scatter_acks_us": round(1e6 * float(np.median(ts_scatter)), 1),
+                           "step_progress_us": round(1e6 * float(np.median(ts_prog)), 1)}
             print(n, out[str(n)], flush=True)
     print(json.dumps(out))
 
