@@ -118,6 +118,38 @@ __device__ __forceinline__ void sort_asc_batcher(u64 (&v)[N]) {
     batcher_impl<N>(v, std::make_integer_sequence<int, Batcher<N>::n>{});
 }
 
+// The same network on the f64 unit: gfx950 has no 64-bit integer min / max, so an integer compare-exchange is
+// v_cmp_u64 + four v_cndmask (5 issue slots), but v_min_f64 + v_max_f64 is 2 — and both return one operand's bits
+// unchanged (f64 denormals are preserved in HIP's default mode; no NaN, no -0 is ever fed in).  to_f64_order maps a
+// u64 to the f64 bit pattern at the same rank: [0, 0x7FF0...) onto the negative doubles from -inf up to the smallest
+// negative denormal, [0x7FF0..., 0xFFE0...] onto +0 .. +inf.  The top 2^53 - 1 values have no pattern left (they
+// would be NaNs): the caller checks f64_order_ok over its keys and takes another form for such a wave (no log index
+// comes near; the bench distribution, rand.Int63n, stays below 2^63).
+constexpr u64 kF64NegInf = 0xFFF0000000000000ull, kF64PosInf = 0x7FF0000000000000ull;
+__device__ __forceinline__ u64 to_f64_order(u64 u) {
+    return (u32)(u >> 32) < (u32)(kF64PosInf >> 32) ? kF64NegInf - u : u - kF64PosInf;
+}
+__device__ __forceinline__ u64 from_f64_order(u64 p) { return (long long)p < 0 ? kF64NegInf - p : p + kF64PosInf; }
+// max over the keys' high words -> every key has a pattern
+__device__ __forceinline__ bool f64_order_ok(u32 top_hi) { return top_hi < 0xFFE00000u; }
+// the same bound for a key that is packed as (key << 2) | tag first
+constexpr u32 kJointF64KeyHi = 0xFFE00000u >> 2;
+
+template <int A, int B, int N>
+__device__ __forceinline__ void cex_f64(u64 (&v)[N]) {
+    const double x = __longlong_as_double((long long)v[A]), y = __longlong_as_double((long long)v[B]);
+    v[A] = (u64)__double_as_longlong(__builtin_fmin(x, y));
+    v[B] = (u64)__double_as_longlong(__builtin_fmax(x, y));
+}
+template <int N, int... K>
+__device__ __forceinline__ void batcher_f64_impl(u64 (&v)[N], std::integer_sequence<int, K...>) {
+    (cex_f64<Batcher<N>::list.ce[K].a, Batcher<N>::list.ce[K].b, N>(v), ...);
+}
+template <int N>
+__device__ __forceinline__ void sort_asc_batcher_f64(u64 (&v)[N]) {
+    batcher_f64_impl<N>(v, std::make_integer_sequence<int, Batcher<N>::n>{});
+}
+
 // Minimal networks up to 8 keys, Batcher's above.
 template <int N>
 __device__ __forceinline__ void sort_keys(u64 (&v)[N]) {
@@ -581,8 +613,9 @@ __device__ __forceinline__ void finish_lane(u64 res, u64 g, u64 G, u64* __restri
 // them in L2); a wave with no joint group skips it.
 // ---------------------------------------------------------------------------
 template <int N, bool NT>
-__device__ __forceinline__ u64 regs_half(const u64* __restrict__ match, u64 stride, int S, u64 m) {
+__device__ __forceinline__ bool regs_half(const u64* __restrict__ match, u64 stride, int S, u64 m, u64& out) {
     u64 a[N];
+    u32 top = 0;
     // wave-uniform base + small per-lane offset: the N addresses stay in SGPRs
     const u64* base = match + (u64)blockIdx.x * kBlock;
     const u32 t = threadIdx.x;
@@ -594,18 +627,55 @@ __device__ __forceinline__ u64 regs_half(const u64* __restrict__ match, u64 stri
         // pair per row), and opaque, so the joint loop re-loads instead of keeping
         // a second copy of every key live
         asm volatile("" : "+s"(p));
-        const u64 v = NT ? __builtin_nontemporal_load(p + t) : p[t];
-        // non-members become key 0; arithmetic mask (no per-key lane-mask SGPR pair)
-        a[s] = v & (0ull - ((m >> s) & 1ull));
+        a[s] = NT ? __builtin_nontemporal_load(p + t) : p[t];
     }
-    sort_asc_batcher<N>(a);
+    // One key at a time, each chained to the next through an empty asm, `top` included: left to itself the compiler
+    // sinks the max over the raw keys below the sort, keeps every raw key for it, and the 64-key kernel spills them
+    // one by one between its loads (1122 us against 587).
+#pragma unroll
+    for (int s = 0; s < N; ++s) {
+        // non-members become key 0; arithmetic mask (no per-key lane-mask SGPR pair)
+        const u64 key = a[s] & (0ull - ((m >> s) & 1ull));
+        const u32 hi = (u32)(key >> 32);
+        top = hi > top ? hi : top;
+        a[s] = to_f64_order(key);
+        if (s + 1 < N) {
+            asm volatile("" : "+v"(a[s]), "+v"(a[s + 1]), "+v"(top));
+        } else {
+            asm volatile("" : "+v"(a[s]), "+v"(top));
+        }
+    }
+    sort_asc_batcher_f64<N>(a);
     const int n = __popcll(m);
     const int pos = N - (n / 2 + 1);
     constexpr int kLo = N - (N / 2 + 1);
     u64 r = a[kLo];
 #pragma unroll
     for (int i = kLo + 1; i < N; ++i) r = (pos == i) ? a[i] : r;
-    return n == 0 ? kU64Max : r;
+    out = n == 0 ? kU64Max : from_f64_order(r);
+    // tested AFTER the sort, like regs_joint_packed's bound: a wave with a key in the top 2^53 has sorted in vain
+    return __all(f64_order_ok(top));
+}
+
+// joint_from_packed_batcher on the f64 unit: a[] holds to_f64_order of the packed entries.  Of a pattern below zero
+// (an entry below 0x7FF0...) the two low bits are those of MINUS the entry: tag 1 and tag 3 change places, so the
+// incoming bit is read as it is and the outgoing one is flipped where both low bits say "incoming".
+template <int N>
+__device__ __forceinline__ u64 joint_from_packed_f64(u64 (&a)[N], u32 q0, u32 q1) {
+    sort_asc_batcher_f64<N>(a);
+    u32 c0 = 0, c1 = 0;
+    u64 p0 = 0, p1 = 0;  // a member's pattern is never 0 (its tag is not): 0 = "no member reached the quorum-th place"
+#pragma unroll
+    for (int i = N - 1; i >= 0; --i) {
+        const u32 lo = (u32)a[i], neg = (u32)(a[i] >> 63);
+        const u32 in0 = lo & 1u, in1 = ((lo >> 1) ^ (neg & lo)) & 1u;
+        c0 += in0;
+        c1 += in1;
+        p0 = (in0 != 0 && c0 == q0) ? a[i] : p0;
+        p1 = (in1 != 0 && c1 == q1) ? a[i] : p1;
+    }
+    const u64 r0 = p0 ? (from_f64_order(p0) >> 2) : kU64Max, r1 = p1 ? (from_f64_order(p1) >> 2) : kU64Max;
+    return r0 < r1 ? r0 : r1;
 }
 
 // 48 / 64 keys: ask for 3 waves per SIMD (<= 168 VGPRs); left alone the
@@ -615,31 +685,41 @@ __device__ __forceinline__ u64 regs_half(const u64* __restrict__ match, u64 stri
 // register per key: 7 operations per compare-exchange against 5, and above 32
 // keys the tag registers spilled, so those waves sorted twice and re-read the
 // keys: 977 us against 547 us non-joint at 2^22 x 64.)  Returns false — wave-
-// uniformly — when some member key is 2^62 or more; the caller then sorts per half.
+// uniformly — when some member key is 0x3FF8000000000000 (2^62 - 2^51) or more: the packed entry would have no f64
+// pattern (to_f64_order); the caller then counts per half.
 template <int N>
 __device__ __forceinline__ bool regs_joint_packed(const u64* __restrict__ match, u64 stride, int S, u64 m0, u64 m1,
                                                   u64& out) {
     u64 a[N];
     const u64* base = match + (u64)blockIdx.x * kBlock;
     const u32 t = threadIdx.x;
-    u64 top = 0;
+    u32 top = 0;
 #pragma unroll
     for (int s = 0; s < N; ++s) {
         const u64* p = base + (u64)(s < S ? s : 0) * stride;  // rows >= S: re-read row 0, tag 0 (masks have no bit there)
         asm volatile("" : "+s"(p));
-        const u64 v = __builtin_nontemporal_load(p + t);
+        a[s] = __builtin_nontemporal_load(p + t);
+    }
+#pragma unroll
+    for (int s = 0; s < N; ++s) {  // one key at a time, as in regs_half
         const u64 tag = ((m0 >> s) & 1ull) | (((m1 >> s) & 1ull) << 1);
-        const u64 key = v & (0ull - (u64)(tag != 0));
-        top |= key;
-        a[s] = (key << 2) | tag;
+        const u64 key = a[s] & (0ull - (u64)(tag != 0));
+        const u32 hi = (u32)(key >> 32);
+        top = hi > top ? hi : top;
+        a[s] = to_f64_order((key << 2) | tag);
+        if (s + 1 < N) {
+            asm volatile("" : "+v"(a[s]), "+v"(a[s + 1]), "+v"(top));
+        } else {
+            asm volatile("" : "+v"(a[s]), "+v"(top));
+        }
     }
     // the bound is tested AFTER the sort: a branch where every key is live costs a hundred spilled registers;
     // a wave that fails it (no real log does) has sorted in vain
-    out = joint_from_packed_batcher<N>(a, (u32)__popcll(m0) / 2 + 1, (u32)__popcll(m1) / 2 + 1);
-    return __all((top >> 62) == 0);
+    out = joint_from_packed_f64<N>(a, (u32)__popcll(m0) / 2 + 1, (u32)__popcll(m1) / 2 + 1);
+    return __all(top < kJointF64KeyHi);
 }
 
-// A joint wave with member keys of 2^62 or more (no real log index is): both halves by counting, in
+// A wave with member keys beyond the one-sort forms' bounds (no real log index is): both halves by counting, in
 // rolled loops that hold no key array — the q-th largest member x of a half is the member with
 // #(members > x) < q <= #(members >= x).  S*S loads per lane, all cache hits; slow and never taken in
 // practice, but the kernel stays bit-exact for every u64 (and keeps no second sorting network alive
@@ -688,13 +768,24 @@ __global__ __launch_bounds__(kBlock, (N > 32 ? 3 : 1)) void k_commit_regs(const 
         m1 &= valid;
     }
     u64 res;
-    if (__any(m1 != 0)) {
-        // Joint wave: one sort serves both halves when every member key is below 2^62
-        // (regs_joint_packed); else one rolled loop over the two halves, keys re-loaded per
-        // half (the second read hits L2).  An empty half yields MaxUint64, the identity of min.
-        if (!regs_joint_packed<N>(match, stride, S, m0, m1, res)) res = joint_by_counting(match, stride, S, g, m0, m1);
-    } else {
-        res = regs_half<N, true>(match, stride, S, m0);
+    const bool joint = __any(m1 != 0);
+    // Joint wave: one sort serves both halves when every member key is below 2^62 - 2^51 (regs_joint_packed).
+    bool per_half = true;
+    if (joint) per_half = !regs_joint_packed<N>(match, stride, S, m0, m1, res);
+    if (per_half) {
+        // A wave with no joint group, or a joint one with keys beyond that bound (rand.Int63n's, bench_test.go:32, are):
+        // one sort per half in a ROLLED loop — a single network in the code, keys re-loaded per half (the second read
+        // hits L2).  An empty half yields MaxUint64, the identity of min.  Keys in the top 2^53: by counting.
+        u64 r = kU64Max;
+        bool ok = true;
+        const int halves = joint ? 2 : 1;
+#pragma unroll 1
+        for (int h = 0; h < halves; ++h) {
+            u64 x;
+            ok &= regs_half<N, true>(match, stride, S, h ? m1 : m0, x);
+            r = x < r ? x : r;
+        }
+        res = ok ? r : joint_by_counting(match, stride, S, g, m0, m1);
     }
     finish_lane<MODE>(res, g, G, commit, lb, rep);
 }

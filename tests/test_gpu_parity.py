@@ -588,3 +588,48 @@ def test_commit_joint_one_sort_path_and_its_bound(oracle, S):
         e.upload_match(planted)
         e.commit()
         assert np.array_equal(e.read_commit(), oracle.batch_committed(planted, m0, m1))
+
+
+@pytest.mark.parametrize("S", [17, 24, 32, 33, 48, 64])
+def test_commit_wide_on_the_f64_sorting_network(oracle, S):
+    """17 slots and up sort on the f64 unit (kernels.h: to_f64_order, cex_f64): a u64 key becomes the f64 bit pattern
+    of the same rank — keys below 0x7FF0... negative doubles, the rest +0 .. +inf — and the top 2^53 keys, which have
+    no pattern, send their wavefront to the counting form.  Keys on both sides of every seam of that map, in every
+    mix: 0, the f64 denormals (every real log index is one), the sign change at 0x7FF0..., the limit at 0xFFE0...,
+    the packed-joint limit at 0x3FF8..., ties; non-joint (uniform and masked) and joint."""
+    rng = np.random.default_rng(2100 + S)
+    G = 8192
+    seams = np.array([0, 1, 2, (1 << 52) - 1, 1 << 52, (1 << 52) + 1, 0x3FF8 << 48, (0x3FF8 << 48) - 1, (0x3FF8 << 48) + 1,
+                      (1 << 62) - 1, 1 << 62, (0x7FF0 << 48) - 1, 0x7FF0 << 48, (0x7FF0 << 48) + 1, (1 << 63) - 1, 1 << 63,
+                      (1 << 63) + 1, (0xFFE0 << 48) - 1, 0xFFE0 << 48], dtype=np.uint64)
+    beyond = np.array([(0xFFE0 << 48) + 1, (0xFFF0 << 48), (1 << 64) - 2, (1 << 64) - 1], dtype=np.uint64)
+    near = seams[rng.integers(0, len(seams), size=(S, G))]
+    jitter = rng.integers(0, 3, size=(S, G), dtype=np.uint64)
+    near = np.where(near >= 2, near - np.uint64(1), near) + jitter  # never past 0xFFE0...+1: see `beyond`
+    near = np.minimum(near, np.uint64(0xFFE0 << 48))
+    wide = rng.integers(0, 0xFFE0 << 47, size=(S, G), dtype=np.uint64) * np.uint64(2)
+    logs = rng.integers(0, 1 << 40, size=(S, G), dtype=np.uint64)
+    sel = rng.random((S, G))
+    match = np.ascontiguousarray(np.where(sel < 0.4, near, np.where(sel < 0.7, wide, logs)).astype(np.uint64))
+    m0, m1 = rand_masks(rng, S, G, joint_frac=0.5, empty_frac=0.03)
+    m1[: G // 2] = 0  # the first half of the wavefronts holds no joint group: regs_half
+    cases = [("masked", m0, m1)]
+    for name, a, b in cases:
+        with raft_amd.Engine(G, S) as e:
+            e.upload_config(a, b)
+            e.upload_match(match)
+            e.commit()
+            assert np.array_equal(e.read_commit(), oracle.batch_committed(match, a, b)), name
+            # keys without a pattern in a few wavefronts only: those count, the others still sort
+            planted = match.copy()
+            gs = rng.choice(G, size=24, replace=False)
+            planted[rng.integers(0, S, size=len(gs)), gs] = beyond[rng.integers(0, len(beyond), size=len(gs))]
+            e.upload_match(planted)
+            e.commit()
+            assert np.array_equal(e.read_commit(), oracle.batch_committed(planted, a, b)), name
+    V = S - (S % 2 == 0)
+    with raft_amd.Engine(G, S) as e:
+        e.set_uniform_config(V)
+        e.upload_match(match)
+        e.commit()
+        assert np.array_equal(e.read_commit(), oracle.batch_committed(match, uniform_voters=V, threads=0))

@@ -156,7 +156,8 @@ def main():
     for Sw in (9, 16, 32, 64):
         G = (1 << 22) >> sh
         rng = np.random.default_rng(Sw)
-        m = rng.integers(0, 1 << 62, size=(Sw, G), dtype=np.uint64)
+        # below 2^62 - 2^51, the bound of K4r's one-sort joint form (every real log index is far below it)
+        m = rng.integers(0, 0x3FF8 << 48, size=(Sw, G), dtype=np.uint64)
         mdt = gu.mask_dtype(Sw)
         full = mdt((1 << Sw) - 1 if Sw < 64 else gu.U64MAX)
         default = "k_commit_masked 256x1 (K2)" if Sw <= 16 else "k_commit_regs (K4r)"
@@ -167,6 +168,12 @@ def main():
                 timed("%s S=%d non-joint" % (kname, Sw), "group", G, 8 * Sw + 2 * mdt().itemsize + 8, e.commit)
                 e.upload_config(np.full(G, full, dtype=mdt), np.full(G, full >> mdt(1), dtype=mdt))
                 timed("%s S=%d joint" % (kname, Sw), "group", G, 8 * Sw + 2 * mdt().itemsize + 8, e.commit)
+                if flags == 0 and Sw > 16:
+                    # the reference's own bench distribution, rand.Int63n (bench_test.go:32): beyond that bound, so a
+                    # joint wave sorts once in vain and then once per half
+                    e.upload_match(gu.dist_a(Sw, Sw, G))
+                    timed("%s S=%d joint, keys up to 2^63 (sorts per half)" % (kname, Sw), "group", G,
+                          8 * Sw + 2 * mdt().itemsize + 8, e.commit)
         del m
 
     # ---- cfg4: tallies ----------------------------------------------------------------------
