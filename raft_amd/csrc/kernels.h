@@ -1018,6 +1018,26 @@ __global__ __launch_bounds__(kBlock) void k_copy_head(const Pair* __restrict__ p
     for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) head[i] = packed[i];
 }
 
+// Up to two small device buffers into the engine's page-locked arena, by one kernel instead of copy commands; a source
+// marked `zero` is cleared behind the copy (the wire status counts: the next call needs no memset).
+struct CopyOut {
+    u32 n;
+    u32 words[2];
+    bool zero[2];
+    u64* src[2];
+    u64* dst[2];
+};
+__global__ __launch_bounds__(kBlock) void k_copy_out(const CopyOut c) {
+    const u32 i = blockIdx.x * kBlock + threadIdx.x;
+#pragma unroll
+    for (u32 k = 0; k < 2; ++k) {
+        if (k < c.n && i < c.words[k]) {
+            c.dst[k][i] = c.src[k][i];
+            if (c.zero[k]) c.src[k][i] = 0;
+        }
+    }
+}
+
 struct ManyPack {
     u32 n;
     u32 first_tile[kManyMax + 1];

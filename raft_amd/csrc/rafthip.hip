@@ -200,6 +200,7 @@ struct rafthip_engine {
     bool have_ids = false, have_term = false;
     bool campaigning = false;  // rafthip_upload_campaign named a vote response type for some group
     u64* d_wire_counts = nullptr;  // [RAFTHIP_WIRE_STATUSES]
+    bool wire_counts_zero = false;  // the last wire call's copy-out kernel left them at zero: no memset in front of the next
     // growable device staging for host-side inputs and outputs, one buffer per role
     void* stage_buf[kStageSlots] = {};
     size_t stage_cap[kStageSlots] = {};
@@ -1549,7 +1550,9 @@ static int wire_run(rafthip_engine* e, const uint8_t* bytes, const uint64_t* off
         if ((rc = stage_reserve(e, kStagePrev, (size_t)n * sizeof(u32)))) return rc;
         d_prev = static_cast<u32*>(e->stage_buf[kStagePrev]);
     }
-    HIP_TRY(hipMemsetAsync(e->d_wire_counts, 0, RAFTHIP_WIRE_STATUSES * sizeof(u64), e->stream));
+    if (!e->wire_counts_zero)
+        HIP_TRY(hipMemsetAsync(e->d_wire_counts, 0, RAFTHIP_WIRE_STATUSES * sizeof(u64), e->stream));
+    e->wire_counts_zero = false;  // until this call's copy-out has zeroed them again
     const bool part = to_progress && prog_part_wanted(e, n);  // K9p: the decode kernel leaves the linking to the tiles
     if (to_progress && !part) {
         if ((rc = clear_stale_heads(e))) return rc;
@@ -1584,21 +1587,32 @@ static int wire_run(rafthip_engine* e, const uint8_t* bytes, const uint64_t* off
     e->zero_copy_pending = false;
     // what is left in device memory comes back through the arena too when it fits: a copy into page-locked memory is
     // one asynchronous transfer, a copy into pageable memory is staged and waited for by the runtime piece by piece
-    auto download = [&](void* dst, const void* src, size_t bytes) -> hipError_t {
+    // (one kernel for both pieces, which also leaves the status counts at zero for the next call: a launch costs a
+    // third of what a copy command does, and the memset in front of the next call goes as well)
+    CopyOut out2{};
+    auto download = [&](void* dst, const void* src, size_t bytes, bool zero_src) -> hipError_t {
         char* d = nullptr;
         char* h = small ? small_take(e, bytes, &d) : nullptr;
+        wait = true;
         if (h && n_after < (int)(sizeof(after) / sizeof(after[0]))) {
             after[n_after].dst = dst;
             after[n_after].src = h;
             after[n_after].bytes = bytes;
             ++n_after;
+            if (bytes % 8 == 0 && out2.n < 2) {
+                out2.src[out2.n] = static_cast<u64*>(const_cast<void*>(src));
+                out2.dst[out2.n] = reinterpret_cast<u64*>(d);
+                out2.words[out2.n] = (u32)(bytes / 8);
+                out2.zero[out2.n] = zero_src;
+                ++out2.n;
+                return hipSuccess;
+            }
             dst = h;
         }
-        wait = true;
         return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, e->stream);
     };
     if (msgs_host) {
-        HIP_TRY(download(out_msgs, d_msgs, (size_t)n * sizeof(Msg)));
+        HIP_TRY(download(out_msgs, d_msgs, (size_t)n * sizeof(Msg), false));
         e->stats.bytes_downloaded += n * sizeof(Msg);
     }
     if (status_host) {
@@ -1606,11 +1620,17 @@ static int wire_run(rafthip_engine* e, const uint8_t* bytes, const uint64_t* off
         e->stats.bytes_downloaded += n;
         wait = true;
     }
-    if (status_counts) HIP_TRY(download(status_counts, e->d_wire_counts, RAFTHIP_WIRE_STATUSES * sizeof(u64)));
+    if (status_counts) HIP_TRY(download(status_counts, e->d_wire_counts, RAFTHIP_WIRE_STATUSES * sizeof(u64), true));
     if (to_progress && actions && act_host) {
         HIP_TRY(hipMemcpyAsync(actions, d_act, (size_t)n, hipMemcpyDeviceToHost, e->stream));
         e->stats.bytes_downloaded += n;
         wait = true;
+    }
+    if (out2.n) {
+        const u32 words = out2.words[0] > out2.words[1] ? out2.words[0] : out2.words[1];
+        hipLaunchKernelGGL(k_copy_out, dim3((words + kBlock - 1) / kBlock), dim3(kBlock), 0, e->stream, out2);
+        HIP_TRY(hipGetLastError());
+        e->wire_counts_zero = (out2.zero[0] && out2.n > 0) || (out2.zero[1] && out2.n > 1);
     }
     if (wait) HIP_TRY(hipStreamSynchronize(e->stream));
     for (int i = 0; i < n_after; ++i) memcpy(after[i].dst, after[i].src, after[i].bytes);
