@@ -125,3 +125,10 @@ def test_header_is_plain_c_and_the_smoke_program_calls_every_entry_point(tmp_pat
     text = open(src).read()
     missing = [s for s in capi.SYMBOLS if not re.search(r"\b%s\(" % s, text)]
     assert not missing, missing
+    # the plain-C latency probe of DESIGN.md section 4 ("a small tick from host memory") builds the same way
+    probe = os.path.join(ROOT, "tools", "small_tick_probe.c")
+    r = subprocess.run(["gcc", "-O2", "-std=c11", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), probe,
+                        "-L", libdir, "-lrafthip", "-Wl,-rpath-link,/opt/rocm/lib",
+                        "-Wl,--unresolved-symbols=ignore-in-shared-libs", "-o", str(tmp_path / "small_tick_probe")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
