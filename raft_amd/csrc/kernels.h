@@ -189,6 +189,24 @@ __device__ __forceinline__ u64 committed_masked(const u64 (&v)[S], u32 m) {
     return m == 0 ? kU64Max : r;
 }
 
+// committed_masked on the f64 unit (9..16 slots): t[] = to_f64_order of the keys, done once for both halves of a joint
+// config; a non-member becomes the pattern of key 0.
+template <int S>
+__device__ __forceinline__ u64 committed_masked_f64(const u64 (&t)[S], u32 m) {
+    m &= (1u << S) - 1u;
+    u64 a[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) a[s] = ((m >> s) & 1u) ? t[s] : kF64NegInf;
+    sort_asc_batcher_f64<S>(a);
+    const int n = __popc(m);
+    const int pos = S - (n / 2 + 1);
+    constexpr int kLo = S - (S / 2 + 1);
+    u64 r = a[kLo];
+#pragma unroll
+    for (int i = kLo + 1; i < S; ++i) r = (pos == i) ? a[i] : r;
+    return m == 0 ? kU64Max : from_f64_order(r);
+}
+
 // JointConfig.CommittedIndex from ONE sort, for keys below 2^62 (every real log index is): the key
 // moves up two bits and carries "member of the incoming half" / "of the outgoing half" in the two
 // bits it vacates, so the membership rides through the plain u64 network for free; after the sort a
@@ -501,6 +519,38 @@ __device__ __forceinline__ void masked_tile(const u64* __restrict__ match, u64 s
     // (Both halves from one sort with the membership in the key's low bits — regs_joint_packed — was tried
     // here as well: no gain at 9..16 slots, where the two sorts hide behind the loads, and at <= 8 slots the
     // extra code cost two waves per SIMD of occupancy.  Measured, not kept: profiles/r02_b_kernels.md.)
+    if constexpr (S >= 12) {
+        // 12..16 slots: the network on the f64 unit (K4r's, kernels.h to_f64_order) unless some key of the wavefront,
+        // member or not, lies in the top 2^53 and has no pattern.  (At 16 slots a joint group costs no more than a plain
+        // one now: 112 -> 95 us per 2^22 groups; at 9 slots the transform costs what the cheaper compare-exchanges
+        // save — 61 / 64 us against 62 / 63 — so the short networks stay on the integer unit.)
+        u32 top = 0;
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const u32 h0 = (u32)(in[c][s].v[0] >> 32), h1 = (u32)(in[c][s].v[1] >> 32);
+                top = h0 > top ? h0 : top;
+                top = h1 > top ? h1 : top;
+            }
+        if (__all(f64_order_ok(top))) {
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    u64 t[S];
+#pragma unroll
+                    for (int s = 0; s < S; ++s) t[s] = to_f64_order(in[c][s].v[j]);
+                    u64 r = committed_masked_f64<S>(t, m0[c].v[j]);
+                    if (wave_joint) {
+                        const u64 r1 = committed_masked_f64<S>(t, m1[c].v[j]);
+                        r = r1 < r ? r1 : r;
+                    }
+                    res[c].v[j] = r;
+                }
+            return;
+        }
+    }
 #pragma unroll
     for (int c = 0; c < CH; ++c)
 #pragma unroll
