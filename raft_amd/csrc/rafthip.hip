@@ -68,9 +68,9 @@ int fail(int code, const char* fmt, ...) {
 u64 round_up(u64 x, u64 a) { return (x + a - 1) / a * a; }
 
 constexpr u64 kMaxRecordsPerLaunch = 1ull << 30;  // scatter / ingest records per kernel launch
-constexpr size_t kSmallArenaBytes = 4u << 20;     // rafthip_engine::h_small
+constexpr size_t kSmallArenaBytes = 16u << 20;    // rafthip_engine::h_small
 constexpr u64 kSmallPairs = 4096;                 // (group, commit) pairs of a report that come back through it
-constexpr u64 kSmallBatch = 32768;                // messages per call up to which the wire entry points use it
+constexpr u64 kSmallBatch = 131072;               // messages per call up to which the wire entry points use it
 
 int mask_bytes_for(u32 S) { return S <= 8 ? 1 : S <= 16 ? 2 : S <= 32 ? 4 : 8; }
 

@@ -276,7 +276,7 @@ def test_step_wire_feeds_the_progress_stepper(oracle, S, cap, form):
 
 
 def test_small_batches_from_host_memory_either_side_of_the_arena(oracle):
-    """Batches of up to 32768 messages from pageable host memory go through the engine's page-locked arena
+    """Batches of up to 131072 messages from pageable host memory go through the engine's page-locked arena
     (rafthip.hip small_take) instead of DMA copies, piece by piece as each fits: the same answers either side of the
     message limit, with a payload larger than the arena, and call after call on one engine."""
     import progress_util as pu
@@ -301,14 +301,14 @@ def test_small_batches_from_host_memory_either_side_of_the_arena(oracle):
         e.upload_ids(ids)
         e.upload_term(term)
         e.upload_read_ctx(cw, cl)
-        for n, fat in [(32769, 0), (32768, 0), (1, 0), (100, 0), (3000, 5), (100, 0), (9000, 0), (1200, 3)]:
+        for n, fat in [(131073, 0), (131072, 0), (1, 0), (100, 0), (3600, 2), (100, 0), (9000, 0), (4500, 3)]:
             blobs, groups = wu.random_batch(rng, n, G, ids, term, ctxs, bad_frac=0.1)
-            for i in range(0, n, fat or n + 1):  # fat > 0: unknown fields that push the payload past the arena's 4 MiB
+            for i in range(0, n, fat or n + 1):  # fat > 0: unknown fields that push the payload past the arena's 16 MiB
                 if fat:
                     pad = bytes(rng.integers(0, 256, size=int(rng.integers(9000, 15000)), dtype=np.uint8))
                     blobs[i] = wu.tag(99, 2) + wu.varint(len(pad)) + pad + blobs[i]
             data, offsets = wu.pack(blobs)
-            assert (len(data) > (4 << 20)) == bool(fat)
+            assert (len(data) > (16 << 20)) == bool(fat)
             want_msgs, want_aux, want_status, want_counts = oracle.decode_wire_msgs(ids, term, cw, cl, data, offsets,
                                                                                     groups)
             msgs, status, counts, act = e.step_wire(data, offsets, groups)
