@@ -188,10 +188,12 @@ struct rafthip_engine {
     // Small batches from / to pageable host memory (the wire entry points): inputs are copied by the CPU into this
     // page-locked, device-mapped arena and read from there by the kernels, outputs are written into it by the kernels
     // and copied out by the CPU after the call's one wait — no DMA copies, each of which costs ~10 us whatever its
-    // size.  Bump-allocated per call; a call that uses it waits for the stream before it returns.
+    // size.  Allocated by the engine's first small batch; bump-allocated per call; a call that uses it waits for the
+    // stream before it returns.
     char* h_small = nullptr;
     char* d_small = nullptr;    // the same memory as the device sees it
     size_t small_used = 0;
+    bool small_failed = false;  // the arena could not be allocated: never tried again
     u64* h_scalar = nullptr;    // pinned, 4 x u64
     u64* d_scalar = nullptr;    // the same words as kernels address them (a total stored there needs no copy back)
 
@@ -555,7 +557,19 @@ static int oneshot_engine(int device, uint64_t G, uint32_t S, const void* in_mas
 char* small_take(rafthip_engine* e, size_t bytes, char** dev) {
     static const bool off = getenv("RAFTHIP_NO_SMALL_ARENA") != nullptr;  // A/B switch for tools/small_tick_probe.py
     const size_t at = (e->small_used + 255) & ~(size_t)255;
-    if (off || !e->h_small || at + bytes > kSmallArenaBytes) return nullptr;
+    if (off || e->small_failed || at + bytes > kSmallArenaBytes) return nullptr;
+    if (!e->h_small) {  // the first small batch of this engine (the caller has made the engine's device current)
+        hipError_t err = hipHostMalloc(reinterpret_cast<void**>(&e->h_small), kSmallArenaBytes,
+                                       hipHostMallocMapped | hipHostMallocCoherent);
+        if (err == hipSuccess) err = hipHostGetDevicePointer(reinterpret_cast<void**>(&e->d_small), e->h_small, 0);
+        if (err != hipSuccess) {  // no page-locked memory to be had: the copy commands still work
+            (void)hipGetLastError();
+            if (e->h_small) (void)hipHostFree(e->h_small);
+            e->h_small = nullptr;
+            e->small_failed = true;
+            return nullptr;
+        }
+    }
     e->small_used = at + bytes;
     *dev = e->d_small + at;
     return e->h_small + at;
@@ -821,13 +835,6 @@ int rafthip_create(const rafthip_config* cfg, rafthip_engine** out) {
         if ((rc = ensure(e, e->d_rejected, 4 * sizeof(u64)))) break;
         hipError_t err = hipHostMalloc(reinterpret_cast<void**>(&e->h_scalar), 4 * sizeof(u64), hipHostMallocDefault);
         if (err == hipSuccess) err = hipHostGetDevicePointer(reinterpret_cast<void**>(&e->d_scalar), e->h_scalar, 0);
-        if (err != hipSuccess) {
-            rc = fail(RAFTHIP_ENOMEM, "hipHostMalloc: %s", hipGetErrorString(err));
-            break;
-        }
-        err = hipHostMalloc(reinterpret_cast<void**>(&e->h_small), kSmallArenaBytes,
-                            hipHostMallocMapped | hipHostMallocCoherent);
-        if (err == hipSuccess) err = hipHostGetDevicePointer(reinterpret_cast<void**>(&e->d_small), e->h_small, 0);
         if (err != hipSuccess) {
             rc = fail(RAFTHIP_ENOMEM, "hipHostMalloc: %s", hipGetErrorString(err));
             break;
