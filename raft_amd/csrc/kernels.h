@@ -662,6 +662,11 @@ __device__ __forceinline__ void finish_lane(u64 res, u64 g, u64 G, u64* __restri
 // staging.  A joint group costs a second pass (keys re-read; first pass leaves
 // them in L2); a wave with no joint group skips it.
 // ---------------------------------------------------------------------------
+// a u64 in global memory: global_load with an SGPR base.  (Against the flat loads the compiler emits when it has lost
+// track of the address space, same box, A/B/A/B: within the 5 % the runs scatter by — kept because it is what the
+// comments below say.)
+typedef __attribute__((address_space(1))) u64 GlobalU64;
+
 template <int N, bool NT>
 __device__ __forceinline__ bool regs_half(const u64* __restrict__ match, u64 stride, int S, u64 m, u64& out) {
     u64 a[N];
@@ -677,7 +682,8 @@ __device__ __forceinline__ bool regs_half(const u64* __restrict__ match, u64 str
         // pair per row), and opaque, so the joint loop re-loads instead of keeping
         // a second copy of every key live
         asm volatile("" : "+s"(p));
-        a[s] = NT ? __builtin_nontemporal_load(p + t) : p[t];
+        const GlobalU64* gp = (const GlobalU64*)p;  // behind the asm the compiler no longer knows: flat loads otherwise
+        a[s] = NT ? __builtin_nontemporal_load(gp + t) : gp[t];
     }
     // One key at a time, each chained to the next through an empty asm, `top` included: left to itself the compiler
     // sinks the max over the raw keys below the sort, keeps every raw key for it, and the 64-key kernel spills them
@@ -748,7 +754,8 @@ __device__ __forceinline__ bool regs_joint_packed(const u64* __restrict__ match,
     for (int s = 0; s < N; ++s) {
         const u64* p = base + (u64)(s < S ? s : 0) * stride;  // rows >= S: re-read row 0, tag 0 (masks have no bit there)
         asm volatile("" : "+s"(p));
-        a[s] = __builtin_nontemporal_load(p + t);
+        const GlobalU64* gp = (const GlobalU64*)p;
+        a[s] = __builtin_nontemporal_load(gp + t);
     }
 #pragma unroll
     for (int s = 0; s < N; ++s) {  // one key at a time, as in regs_half
