@@ -633,3 +633,20 @@ def test_commit_wide_on_the_f64_sorting_network(oracle, S):
         e.upload_match(match)
         e.commit()
         assert np.array_equal(e.read_commit(), oracle.batch_committed(match, uniform_voters=V, threads=0))
+
+
+@pytest.mark.parametrize("S", [16, 24, 64])
+def test_commit_wide_a_quarter_million_groups_both_distributions(oracle, S):
+    """The f64-unit kernels over 2^18 groups (every tile shape, many wavefronts per CU): the reference's bench
+    distribution (rand.Int63n: a joint wave is beyond the one-sort bound and sorts per half) and the raft-like one
+    (indexes near 2^40 with lagging followers, a few cells >= 2^63), non-joint and joint masks mixed."""
+    G = 1 << 18
+    rng = np.random.default_rng(2300 + S)
+    m0, m1 = rand_masks(rng, S, G, joint_frac=0.5, empty_frac=0.01)
+    m1[G // 4: G // 2] = 0  # whole wavefronts without a joint group
+    with raft_amd.Engine(G, S) as e:
+        e.upload_config(m0, m1)
+        for match in (gu.dist_a(77 + S, S, G), gu.dist_b(78 + S, S, G)):
+            e.upload_match(match)
+            e.commit()
+            assert np.array_equal(e.read_commit(), oracle.batch_committed(match, m0, m1))
