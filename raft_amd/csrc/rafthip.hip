@@ -71,6 +71,9 @@ constexpr u64 kMaxRecordsPerLaunch = 1ull << 30;  // scatter / ingest records pe
 constexpr size_t kSmallArenaBytes = 16u << 20;    // rafthip_engine::h_small
 constexpr u64 kSmallPairs = 4096;                 // (group, commit) pairs of a report that come back through it
 constexpr u64 kSmallBatch = 131072;               // messages per call up to which the wire entry points use it
+constexpr u64 kSmallRecords = 16384;              // 16-byte records per call up to which the record entry points do: their
+                                                  // kernels read a record more than once, over the link when it lies in the
+                                                  // arena (break-even near 30000 records, tools/small_tick_probe.py)
 
 int mask_bytes_for(u32 S) { return S <= 8 ? 1 : S <= 16 ? 2 : S <= 32 ? 4 : 8; }
 
@@ -596,7 +599,7 @@ static int stage_records(rafthip_engine* e, const void* recs, uint64_t n, const 
         }
     }
     (void)hipGetLastError();  // plain host memory reports an error on some runtimes
-    if (n <= kSmallBatch) {   // a small batch: through the page-locked arena, no DMA copy (every caller waits when staged)
+    if (n <= kSmallRecords) {  // a small batch: through the page-locked arena, no DMA copy (every caller waits when staged)
         e->small_used = 0;
         char* d = nullptr;
         if (char* h = small_take(e, n * sizeof(Ack), &d)) {
@@ -2139,7 +2142,7 @@ int rafthip_step_progress(rafthip_engine* e, const rafthip_msg* msgs, const uint
     e->small_used = 0;
     if ((rc = stage_records(e, msgs, n, &d_recs, &staged))) return rc;
     const void* d_aux = nullptr;
-    const bool small = staged && !is_device_ptr(d_recs) && n <= kSmallBatch;  // stage_records took the arena
+    const bool small = staged && !is_device_ptr(d_recs) && n <= kSmallRecords;  // stage_records took the arena
     if (aux && (rc = stage_input(e, kStageAux, aux, (size_t)n * sizeof(u64), &d_aux, small))) return rc;
     bool act_host = !actions || !is_device_ptr(actions);
     uint8_t* d_act = actions;
