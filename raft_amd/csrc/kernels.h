@@ -742,7 +742,7 @@ __device__ __forceinline__ u64 joint_from_packed_f64(u64 (&a)[N], u32 q0, u32 q1
 // keys the tag registers spilled, so those waves sorted twice and re-read the
 // keys: 977 us against 547 us non-joint at 2^22 x 64.)  Returns false — wave-
 // uniformly — when some member key is 0x3FF8000000000000 (2^62 - 2^51) or more: the packed entry would have no f64
-// pattern (to_f64_order); the caller then counts per half.
+// pattern (to_f64_order); the caller then sorts once per half (regs_half).
 template <int N>
 __device__ __forceinline__ bool regs_joint_packed(const u64* __restrict__ match, u64 stride, int S, u64 m0, u64 m1,
                                                   u64& out) {
