@@ -804,6 +804,7 @@ __device__ __forceinline__ u64 joint_by_counting(const u64* __restrict__ match, 
     return r0 < r1 ? r0 : r1;
 }
 
+// (24 / 32 keys asked to fit 5 or 6 waves per SIMD spill a little and lose a quarter: 192 -> 250 / 238 us at S = 32.)
 template <int N, typename MaskT, int MODE>
 __global__ __launch_bounds__(kBlock, (N > 32 ? 3 : 1)) void k_commit_regs(const u64* __restrict__ match, u64 stride, u64 G,
                                                         int S, const MaskT* __restrict__ in_mask,
