@@ -650,3 +650,36 @@ def test_commit_wide_a_quarter_million_groups_both_distributions(oracle, S):
             e.upload_match(match)
             e.commit()
             assert np.array_equal(e.read_commit(), oracle.batch_committed(match, m0, m1))
+
+
+def test_commit_changed_short_reports_through_the_arena(oracle):
+    """A report of at most 4096 pairs into pageable memory comes back through the engine's page-locked arena
+    (rafthip.hip commit_report, k_copy_head), a longer one by a second copy: the same pairs either side of that limit,
+    with a destination smaller than the report, and again after a long report."""
+    G, S = 20000, 5
+    rng = np.random.default_rng(2400)
+    match = rand_match(rng, S, G)
+    with raft_amd.Engine(G, S) as e:
+        e.set_uniform_config(S)
+        e.upload_match(match)
+        e.commit()
+        for k in (0, 1, 4095, 4096, 4097, 9000, 3, G, 4096):
+            gs = np.sort(rng.choice(G, size=k, replace=False))
+            before = oracle.batch_committed(match, uniform_voters=S, threads=0)
+            match[:, gs] = match[:, gs] + np.uint64(1) + rng.integers(0, 5, size=(S, k), dtype=np.uint64)
+            e.upload_match(match)
+            want = oracle.batch_committed(match, uniform_voters=S, threads=0)
+            changed = np.flatnonzero(want != before)
+            for room in (G, 4096, max(1, len(changed) // 2)):
+                pairs, n = e.commit_changed(max_pairs=room)
+                if room == G:
+                    assert n == len(changed)
+                    assert np.array_equal(pairs["group"], changed) and np.array_equal(pairs["commit"], want[changed])
+                else:  # nothing changes between two passes over the same planes: an empty report, whatever the room
+                    assert n == 0 and len(pairs) == 0
+            # a destination smaller than the report: the first `room` pairs, the full count
+            e.upload_commit(before)
+            room = max(1, len(changed) // 2)
+            pairs, n = e.commit_changed(max_pairs=room)
+            assert n == len(changed) and np.array_equal(pairs["group"], changed[:min(room, n)])
+            assert np.array_equal(pairs["commit"], want[changed][:min(room, n)])
