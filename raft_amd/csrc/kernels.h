@@ -189,6 +189,19 @@ __device__ __forceinline__ u64 committed_masked(const u64 (&v)[S], u32 m) {
     return m == 0 ? kU64Max : r;
 }
 
+template <int N, int... K>
+__device__ __forceinline__ void sort_f64_impl(u64 (&v)[N], std::integer_sequence<int, K...>) {
+    (cex_f64<SortNet<N>::ce[K].a, SortNet<N>::ce[K].b, N>(v), ...);
+}
+template <int N>
+__device__ __forceinline__ void sort_keys_f64(u64 (&v)[N]) {
+    if constexpr (N <= 8) {
+        if constexpr (SortNet<N>::n > 0) sort_f64_impl<N>(v, std::make_integer_sequence<int, SortNet<N>::n>{});
+    } else {
+        sort_asc_batcher_f64<N>(v);
+    }
+}
+
 // committed_masked on the f64 unit (9..16 slots): t[] = to_f64_order of the keys, done once for both halves of a joint
 // config; a non-member becomes the pattern of key 0.
 template <int S>
@@ -197,7 +210,7 @@ __device__ __forceinline__ u64 committed_masked_f64(const u64 (&t)[S], u32 m) {
     u64 a[S];
 #pragma unroll
     for (int s = 0; s < S; ++s) a[s] = ((m >> s) & 1u) ? t[s] : kF64NegInf;
-    sort_asc_batcher_f64<S>(a);
+    sort_keys_f64<S>(a);
     const int n = __popc(m);
     const int pos = S - (n / 2 + 1);
     constexpr int kLo = S - (S / 2 + 1);
@@ -490,6 +503,9 @@ __global__ __launch_bounds__(kCommitBlock) void k_commit_uniform_many_report(con
 // keys per lane) and 16-bit masks; a uniform config of more than 8 voters
 // (in_mask == NULL) runs here too.
 // ---------------------------------------------------------------------------
+// slots from which K2 sorts on the f64 unit (same box, half of the groups joint, 2^24 groups: 4 slots 113 -> 115 us,
+// 5 slots 137 -> 135, 6 slots -4 %, 8 slots 213 -> 209: the transform pays from six keys on)
+constexpr int kMaskedF64From = 6;
 // One tile of K2: res[c].v[j] = the joint commit index of group base + c*2*BLOCK + j.
 template <int S, typename MaskT, int BLOCK, int CH>
 __device__ __forceinline__ void masked_tile(const u64* __restrict__ match, u64 stride, const MaskT* __restrict__ in_mask,
@@ -519,11 +535,12 @@ __device__ __forceinline__ void masked_tile(const u64* __restrict__ match, u64 s
     // (Both halves from one sort with the membership in the key's low bits — regs_joint_packed — was tried
     // here as well: no gain at 9..16 slots, where the two sorts hide behind the loads, and at <= 8 slots the
     // extra code cost two waves per SIMD of occupancy.  Measured, not kept: profiles/r02_b_kernels.md.)
-    if constexpr (S >= 12) {
-        // 12..16 slots: the network on the f64 unit (K4r's, kernels.h to_f64_order) unless some key of the wavefront,
-        // member or not, lies in the top 2^53 and has no pattern.  (At 16 slots a joint group costs no more than a plain
-        // one now: 112 -> 95 us per 2^22 groups; at 9 slots the transform costs what the cheaper compare-exchanges
-        // save — 61 / 64 us against 62 / 63 — so the short networks stay on the integer unit.)
+    if constexpr (S >= kMaskedF64From) {
+        // The network on the f64 unit (K4r's, kernels.h to_f64_order) unless some key of the wavefront, member or not,
+        // lies in the top 2^53 and has no pattern: the keys are transformed once, both halves of a joint group sort
+        // with v_min_f64 / v_max_f64.  Same box, A/B/A/B: cfg3's joint mix at 6 slots 164 -> 158 us per 2^24 groups,
+        // twelve shards of it in one launch 124 -> 120, one launch each 186 -> 167; 9 slots 60 / 61 either way; at 16
+        // slots a joint group costs no more than a plain one now (112 -> 94 us per 2^22 groups).
         u32 top = 0;
 #pragma unroll
         for (int c = 0; c < CH; ++c)

@@ -590,9 +590,9 @@ def test_commit_joint_one_sort_path_and_its_bound(oracle, S):
         assert np.array_equal(e.read_commit(), oracle.batch_committed(planted, m0, m1))
 
 
-@pytest.mark.parametrize("S", [12, 13, 16, 17, 24, 32, 33, 48, 64])
+@pytest.mark.parametrize("S", [6, 7, 8, 9, 12, 13, 16, 17, 24, 32, 33, 48, 64])
 def test_commit_wide_on_the_f64_sorting_network(oracle, S):
-    """12 slots and up sort on the f64 unit (kernels.h: to_f64_order, cex_f64; K2 at 12..16, K4r above): a u64 key becomes the f64 bit pattern
+    """6 slots and up sort on the f64 unit (kernels.h: to_f64_order, cex_f64; K2 up to 16, K4r above): a u64 key becomes the f64 bit pattern
     of the same rank — keys below 0x7FF0... negative doubles, the rest +0 .. +inf — and the top 2^53 keys, which have
     no pattern, send their wavefront to the counting form.  Keys on both sides of every seam of that map, in every
     mix: 0, the f64 denormals (every real log index is one), the sign change at 0x7FF0..., the limit at 0xFFE0...,

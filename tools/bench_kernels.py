@@ -126,6 +126,22 @@ def main():
         timed("k_commit_masked<6> no joint group (K2)", "group", G, 8 * 6 + 2 + 8, e.commit)
     del m
 
+    # ---- K2 at its other slot counts: random masks, half of the groups joint (where the f64 network starts to pay) ----
+    for Sk in (3, 4, 5, 8):
+        name = "k_commit_masked<%d> random masks, half joint (K2)" % Sk
+        if args.only and args.only not in name:
+            continue
+        G = (1 << 24) >> sh
+        rng = np.random.default_rng(100 + Sk)
+        m = gu.dist_a(0x5EED0030 + Sk, Sk, G)
+        k0 = rng.integers(1, 1 << Sk, size=G).astype(np.uint8)
+        k1 = np.where(rng.random(G) < 0.5, rng.integers(1, 1 << Sk, size=G), 0).astype(np.uint8)
+        with raft_amd.Engine(G, Sk, stream=stream.cuda_stream) as e:
+            e.upload_config(k0, k1)
+            e.upload_match(m)
+            timed(name, "group", G, 8 * Sk + 2 + 8, e.commit)
+        del m, k0, k1
+
     # ---- K2m: a host in the middle of a conf change — 12 shards of 2^20 groups, cfg3 mix, one launch ----------
     if not args.only or args.only in "k_commit_masked_many<6> (K2m)":
         from raft_amd.capi import EngineSet
