@@ -592,7 +592,7 @@ def test_commit_joint_one_sort_path_and_its_bound(oracle, S):
 
 @pytest.mark.parametrize("S", [6, 7, 8, 9, 12, 13, 16, 17, 24, 32, 33, 48, 64])
 def test_commit_wide_on_the_f64_sorting_network(oracle, S):
-    """6 slots and up sort on the f64 unit (kernels.h: to_f64_order, cex_f64; K2 up to 16, K4r above): a u64 key becomes the f64 bit pattern
+    """6 slots and up sort on the f64 unit (kernels.h: to_f64_order, cex_f64; K1 and K2 up to 8 / 16, K4r above): a u64 key becomes the f64 bit pattern
     of the same rank — keys below 0x7FF0... negative doubles, the rest +0 .. +inf — and the top 2^53 keys, which have
     no pattern, send their wavefront to the counting form.  Keys on both sides of every seam of that map, in every
     mix: 0, the f64 denormals (every real log index is one), the sign change at 0x7FF0..., the limit at 0xFFE0...,
@@ -627,12 +627,19 @@ def test_commit_wide_on_the_f64_sorting_network(oracle, S):
             e.upload_match(planted)
             e.commit()
             assert np.array_equal(e.read_commit(), oracle.batch_committed(planted, a, b)), name
-    V = S - (S % 2 == 0)
-    with raft_amd.Engine(G, S) as e:
-        e.set_uniform_config(V)
-        e.upload_match(match)
-        e.commit()
-        assert np.array_equal(e.read_commit(), oracle.batch_committed(match, uniform_voters=V, threads=0))
+    # uniform configs (K1 up to 8 voters, on the f64 unit from 6: kernels.h uniform_tile), odd and even, with and
+    # without keys that have no pattern; changed pairs through the reporting form of the same tile
+    for V in (S - 1, S):
+        with raft_amd.Engine(G, S) as e:
+            e.set_uniform_config(V)
+            for planes in (match, planted):
+                e.upload_match(planes)
+                want = oracle.batch_committed(planes, uniform_voters=V, threads=0)
+                before = e.read_commit()
+                pairs, n = e.commit_changed()
+                assert np.array_equal(e.read_commit(), want), V
+                ch = np.flatnonzero(before != want)
+                assert n == len(ch) and np.array_equal(pairs["group"], ch) and np.array_equal(pairs["commit"], want[ch]), V
 
 
 @pytest.mark.parametrize("S", [16, 24, 64])
