@@ -616,6 +616,59 @@ int rafthip_read_quorum_active(rafthip_engine *e, uint64_t first, uint64_t count
  * (rafthip_upload_self).  Read the verdict with rafthip_read_quorum_active. */
 int rafthip_check_quorum(rafthip_engine *e);
 
+/* ---- RawNode.Tick for every group — rawnode.go:64-66 ----------------------
+ * The caller of the two steps above and of the heartbeat fan-out: r.tick() is
+ * tickHeartbeat for a leader (raft.go:835-862) and tickElection for a follower,
+ * candidate or pre-candidate (raft.go:823-832).  Per-group state, as planes:
+ *   election_elapsed, heartbeat_elapsed   r.electionElapsed, r.heartbeatElapsed
+ *   randomized_timeout                    r.randomizedElectionTimeout (raft.go:1988-1990,
+ *                                         drawn by the host's generator)
+ *   role                                  r.state, StateType of raft.go:48-53
+ *                                         (0 follower, 1 candidate, 2 leader, 3 pre-candidate)
+ *   flags                                 RAFTHIP_TICKF_PROMOTABLE = r.promotable() (raft.go:1883-1886),
+ *                                         RAFTHIP_TICKF_TRANSFER = r.leadTransferee != None
+ * and for the engine ElectionTick, HeartbeatTick, CheckQuorum of raft.Config
+ * (raft.go:128-138,219-224; refused as Config.validate refuses them, raft.go:296-302).
+ * Counters are uint32 where the reference has int: keep them below 2^31.
+ *
+ * One pass advances every group by one tick and leaves an action byte per group:
+ *   RAFTHIP_TICK_HUP             tickElection fired: the host steps MsgHup (raft.go:826-831);
+ *                                election_elapsed is back at 0
+ *   RAFTHIP_TICK_CHECK_QUORUM    an election timeout passed on a leader with CheckQuorum: the
+ *                                MsgCheckQuorum step of raft.go:1231-1243 has been done on the
+ *                                group's RecentActive bits (rafthip_upload_active / _self; what
+ *                                rafthip_check_quorum does, for this group only)
+ *   RAFTHIP_TICK_STEP_DOWN       ... and the quorum was not active: role is follower, both timers 0,
+ *                                the transfer flag and every RecentActive bit cleared
+ *                                (becomeFollower -> reset, raft.go:864-871,760-789); the host does the
+ *                                rest of reset: a new randomized timeout, rafthip_reset_match,
+ *                                rafthip_reset_votes, the Progress rows
+ *   RAFTHIP_TICK_ABORT_TRANSFER  a leader's transfer did not finish within an election timeout
+ *                                (raft.go:846-849); the flag is cleared
+ *   RAFTHIP_TICK_BEAT            heartbeat_elapsed reached HeartbeatTick on a (still) leader: the host
+ *                                steps MsgBeat -> bcastHeartbeat (rafthip_emit_heartbeats)
+ * counts (may be NULL: nothing is copied back and the call does not wait):
+ * counts[b] = groups whose action byte has bit b. */
+#define RAFTHIP_TICK_HUP 1u
+#define RAFTHIP_TICK_CHECK_QUORUM 2u
+#define RAFTHIP_TICK_STEP_DOWN 4u
+#define RAFTHIP_TICK_ABORT_TRANSFER 8u
+#define RAFTHIP_TICK_BEAT 16u
+#define RAFTHIP_TICK_ACTIONS 5
+#define RAFTHIP_TICKF_PROMOTABLE 1u
+#define RAFTHIP_TICKF_TRANSFER 2u
+int rafthip_tick_config(rafthip_engine *e, uint32_t election_tick, uint32_t heartbeat_tick, int check_quorum);
+/* Any of the five sources / destinations may be NULL (that plane is left alone);
+ * planes never uploaded hold zeros: a follower that is not promotable. */
+int rafthip_upload_tick_state(rafthip_engine *e, uint64_t first, uint64_t count, const uint32_t *election_elapsed,
+                              const uint32_t *heartbeat_elapsed, const uint32_t *randomized_timeout,
+                              const uint8_t *role, const uint8_t *flags);
+int rafthip_read_tick_state(rafthip_engine *e, uint64_t first, uint64_t count, uint32_t *election_elapsed,
+                            uint32_t *heartbeat_elapsed, uint32_t *randomized_timeout, uint8_t *role,
+                            uint8_t *flags);
+int rafthip_tick(rafthip_engine *e, uint64_t *counts);
+int rafthip_read_tick_actions(rafthip_engine *e, uint64_t first, uint64_t count, uint8_t *dst);
+
 /* ReadIndex ack quorum — Voters.VoteResult(acks) at raft.go:1552 with the
  * yes-only map of read_only.go:68-76.  Output: VoteResult per group. */
 int rafthip_ack_quorum(rafthip_engine *e);

@@ -110,6 +110,9 @@ def lib():
         L.oracle_decode_wire_msgs.restype = None
         L.oracle_decode_wire_msgs.argtypes = [C.c_uint64, C.c_int, vp, C.c_uint64, vp, vp, vp, vp, C.c_uint64, vp, vp,
                                               C.c_uint64, vp, vp, vp, vp, vp, vp, C.c_uint64]
+        L.oracle_batch_tick.restype = None
+        L.oracle_batch_tick.argtypes = [C.c_uint64, C.c_int, vp, vp, vp, vp, vp, C.c_uint32, C.c_uint32, C.c_int,
+                                        vp, vp, vp, vp, C.c_int, C.c_int, vp, vp]
         L.oracle_batch_check_quorum.restype = None
         L.oracle_batch_check_quorum.argtypes = [C.c_uint64, C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp]
         L.oracle_batch_heartbeat_commit.restype = None
@@ -454,6 +457,24 @@ def bcast_heartbeat(match, committed, ids, term, read_ctx, read_ctx_len, self_ma
       _vp(_chk(term, np.uint64)), _vp(_chk(read_ctx, np.uint64)), _vp(_chk(read_ctx_len, np.uint8)), _vp(self_mask),
       self_mask.dtype.itemsize, _vp(out), msg_stride, _vp(lens))
     return out, lens
+
+
+def batch_tick(election_elapsed, heartbeat_elapsed, randomized_timeout, state, flags, election_timeout,
+               heartbeat_timeout, check_quorum, nslots, active, self_mask, in_mask=None, out_mask=None,
+               learner_mask=None, uniform_voters=0):
+    """RawNode.Tick for every group (raft.go:823-862): mutates the two elapsed planes, state, flags and active in
+    place; returns the action byte per group."""
+    G = len(state)
+    for a, dt in ((election_elapsed, np.uint32), (heartbeat_elapsed, np.uint32), (randomized_timeout, np.uint32),
+                  (state, np.uint8), (flags, np.uint8)):
+        _chk(a, dt)
+        assert len(a) == G
+    act = np.empty(G, dtype=np.uint8)
+    lib().oracle_batch_tick(G, nslots, _vp(election_elapsed), _vp(heartbeat_elapsed), _vp(randomized_timeout),
+                            _vp(state), _vp(flags), election_timeout, heartbeat_timeout, int(bool(check_quorum)),
+                            _vp(_chk(active)), _vp(_chk(in_mask)), _vp(_chk(out_mask)), _vp(_chk(learner_mask)),
+                            active.dtype.itemsize, uniform_voters, _vp(_chk(self_mask)), _vp(act))
+    return act
 
 
 def batch_check_quorum(active, nslots, self_mask, in_mask=None, out_mask=None, learner_mask=None,

@@ -1155,6 +1155,68 @@ ORACLE_API void oracle_batch_check_quorum(uint64_t G, int nslots, void *active, 
     }
 }
 
+/*
+ * rawnode.go:64-66 — RawNode.Tick for G groups: r.tick() is tickHeartbeat for a leader (raft.go:835-862), tickElection
+ * for every other state (raft.go:823-832).  Per group the fields of `raft` the two functions touch:
+ * electionElapsed, heartbeatElapsed, randomizedElectionTimeout, state (StateType, raft.go:48-53), promotable()
+ * (flag bit 0, raft.go:1883-1886) and leadTransferee != None (flag bit 1); electionTimeout, heartbeatTimeout and
+ * checkQuorum are the same for all (raft.Config).  Step(MsgCheckQuorum) is restated from raft.go:1231-1243 with
+ * becomeFollower -> reset (raft.go:864-871,760-789) as far as this state reaches: both timers 0, the transfer
+ * aborted, every Progress fresh (RecentActive false).  action bits: 1 MsgHup stepped, 2 MsgCheckQuorum stepped,
+ * 4 stepped down, 8 transfer aborted, 16 MsgBeat stepped.
+ */
+ORACLE_API void oracle_batch_tick(uint64_t G, int nslots, uint32_t *election_elapsed, uint32_t *heartbeat_elapsed,
+                                  const uint32_t *randomized_timeout, uint8_t *state, uint8_t *flags,
+                                  uint32_t election_timeout, uint32_t heartbeat_timeout, int check_quorum,
+                                  void *active, const void *in_mask, const void *out_mask, const void *learner_mask,
+                                  int mask_bytes, int uniform_voters, const void *self_mask, uint8_t *action) {
+    enum { FOLLOWER = 0, LEADER = 2 };
+    for (uint64_t g = 0; g < G; g++) {
+        uint8_t act = 0;
+        if (state[g] == LEADER) { /* tickHeartbeat */
+            heartbeat_elapsed[g]++;
+            election_elapsed[g]++;
+            if (election_elapsed[g] >= election_timeout) {
+                election_elapsed[g] = 0;
+                if (check_quorum) {
+                    act |= 2;
+                    uint8_t qa = 0;
+                    const char *a = (const char *)active + g * (uint64_t)mask_bytes;
+                    oracle_batch_quorum_active(1, nslots, a, in_mask ? (const char *)in_mask + g * (uint64_t)mask_bytes : NULL,
+                                               out_mask ? (const char *)out_mask + g * (uint64_t)mask_bytes : NULL,
+                                               learner_mask ? (const char *)learner_mask + g * (uint64_t)mask_bytes : NULL,
+                                               mask_bytes, uniform_voters, &qa);
+                    if (!qa) { /* raft.go:1232-1235 */
+                        act |= 4;
+                        state[g] = FOLLOWER;
+                        election_elapsed[g] = 0;
+                        heartbeat_elapsed[g] = 0;
+                        flags[g] &= (uint8_t)~2u; /* abortLeaderTransfer */
+                        store_mask(active, mask_bytes, g, 0);
+                    } else { /* raft.go:1236-1242 */
+                        store_mask(active, mask_bytes, g, load_mask(active, mask_bytes, g) & load_mask(self_mask, mask_bytes, g));
+                    }
+                }
+                if (state[g] == LEADER && (flags[g] & 2)) { /* raft.go:846-849 */
+                    act |= 8;
+                    flags[g] &= (uint8_t)~2u;
+                }
+            }
+            if (state[g] == LEADER && heartbeat_elapsed[g] >= heartbeat_timeout) { /* raft.go:852-861 */
+                heartbeat_elapsed[g] = 0;
+                act |= 16;
+            }
+        } else { /* tickElection */
+            election_elapsed[g]++;
+            if ((flags[g] & 1) && election_elapsed[g] >= randomized_timeout[g]) {
+                election_elapsed[g] = 0;
+                act |= 1;
+            }
+        }
+        action[g] = act;
+    }
+}
+
 /* raft.go:669-685 — sendHeartbeat's commit := min(pr.Match, r.raftLog.committed). */
 ORACLE_API void oracle_batch_heartbeat_commit(uint64_t G, int nslots, const uint64_t *match,
                                               uint64_t stride, const uint64_t *committed,

@@ -51,8 +51,15 @@ SYMBOLS = [
     "rafthip_comm_info", "rafthip_commit_allgather", "rafthip_commit_allgather_many", "rafthip_commit_many",
     "rafthip_commit_allgather_dense", "rafthip_commit_allgather_dense_many", "rafthip_commit_report_many",
     "rafthip_init_progress_row",
+    "rafthip_tick_config", "rafthip_upload_tick_state", "rafthip_read_tick_state", "rafthip_tick",
+    "rafthip_read_tick_actions",
 ]
 COMM_ID_BYTES = 128
+# RawNode.Tick (rafthip.h RAFTHIP_TICK_*): StateType of raft.go:48-53, action bits, flag bits
+STATE_FOLLOWER, STATE_CANDIDATE, STATE_LEADER, STATE_PRE_CANDIDATE = 0, 1, 2, 3
+TICK_HUP, TICK_CHECK_QUORUM, TICK_STEP_DOWN, TICK_ABORT_TRANSFER, TICK_BEAT = 1, 2, 4, 8, 16
+TICK_ACTIONS = 5
+TICKF_PROMOTABLE, TICKF_TRANSFER = 1, 2
 MSG_VOTE_RESP, MSG_PRE_VOTE_RESP = 6, 18
 
 STATE_PROBE, STATE_REPLICATE, STATE_SNAPSHOT, PROGRESS_PAUSED = 0, 1, 2, 4
@@ -163,6 +170,11 @@ def load_library():
         "rafthip_heartbeat_commit": (i32, [vp, u64, u64, vp, u64]),
         "rafthip_upload_self": (i32, [vp, u64, u64, vp]),
         "rafthip_check_quorum": (i32, [vp]),
+        "rafthip_tick_config": (i32, [vp, C.c_uint32, C.c_uint32, C.c_int]),
+        "rafthip_upload_tick_state": (i32, [vp, u64, u64, vp, vp, vp, vp, vp]),
+        "rafthip_read_tick_state": (i32, [vp, u64, u64, vp, vp, vp, vp, vp]),
+        "rafthip_tick": (i32, [vp, vp]),
+        "rafthip_read_tick_actions": (i32, [vp, u64, u64, vp]),
         "rafthip_read_active": (i32, [vp, u64, u64, vp]),
         "rafthip_read_acks": (i32, [vp, u64, u64, vp]),
         "rafthip_read_term_range": (i32, [vp, u64, u64, vp, vp]),
@@ -550,6 +562,47 @@ class Engine:
 
     def check_quorum(self):
         _check(self._L.rafthip_check_quorum(self._h))
+
+    def tick_config(self, election_tick, heartbeat_tick, check_quorum):
+        _check(self._L.rafthip_tick_config(self._h, election_tick, heartbeat_tick, int(bool(check_quorum))))
+
+    def upload_tick_state(self, election_elapsed=None, heartbeat_elapsed=None, randomized_timeout=None, role=None,
+                          flags=None, first=0, count=None):
+        """Any plane may be None (left alone).  uint32 timers, uint8 role / flags."""
+        first, count = self._range(first, count)
+        planes = []
+        for a, dt in ((election_elapsed, np.uint32), (heartbeat_elapsed, np.uint32), (randomized_timeout, np.uint32),
+                      (role, np.uint8), (flags, np.uint8)):
+            if a is None:
+                planes.append(None)
+                continue
+            a = np.ascontiguousarray(a, dtype=dt)
+            if len(a) != count:
+                raise ValueError("tick plane of %d entries for %d groups" % (len(a), count))
+            planes.append(a)
+        _check(self._L.rafthip_upload_tick_state(self._h, first, count, *[None if a is None else _ptr(a) for a in planes]))
+
+    def read_tick_state(self, first=0, count=None):
+        """(election_elapsed, heartbeat_elapsed, randomized_timeout, role, flags)."""
+        first, count = self._range(first, count)
+        outs = [np.empty(count, dtype=np.uint32) for _ in range(3)] + [np.empty(count, dtype=np.uint8) for _ in range(2)]
+        _check(self._L.rafthip_read_tick_state(self._h, first, count, *[_ptr(a) for a in outs]))
+        return tuple(outs)
+
+    def tick(self, counts=True):
+        """RawNode.Tick for every group.  Returns the per-action group counts (TICK_ACTIONS words), or None."""
+        if not counts:
+            _check(self._L.rafthip_tick(self._h, None))
+            return None
+        out = np.zeros(TICK_ACTIONS, dtype=np.uint64)
+        _check(self._L.rafthip_tick(self._h, _ptr(out)))
+        return out
+
+    def read_tick_actions(self, first=0, count=None):
+        first, count = self._range(first, count)
+        out = np.empty(count, dtype=np.uint8)
+        _check(self._L.rafthip_read_tick_actions(self._h, first, count, _ptr(out)))
+        return out
 
     def read_active(self, first=0, count=None):
         first, count = self._range(first, count)

@@ -25,6 +25,7 @@
 #include "scatter_part.h"
 #include "progress_part.h"
 #include "wire.h"
+#include "tick.h"
 #include "rafthip.h"
 #include "rafthip_internal.h"
 
@@ -217,6 +218,17 @@ struct rafthip_engine {
     bool heads_dirty = false;  // a link pass ran without its apply pass: list heads may be left in the records
     ProgPlanes pp{};
     u64* first_index = nullptr; // raftLog.firstIndex() per group
+
+    // RawNode.Tick for every group (tick.h)
+    u32* tick_el = nullptr;         // electionElapsed
+    u32* tick_hb = nullptr;         // heartbeatElapsed
+    u32* tick_rt = nullptr;         // randomizedElectionTimeout
+    uint8_t* tick_role = nullptr;   // StateType
+    uint8_t* tick_flags = nullptr;  // RAFTHIP_TICKF_*
+    uint8_t* tick_action = nullptr; // RAFTHIP_TICK_* of the last pass
+    u64* d_tick_counts = nullptr;   // [kTickCountCopies][kTickCountStride]
+    u32 election_timeout = 0, heartbeat_timeout = 0;  // 0: rafthip_tick_config has not been called
+    bool check_quorum = false;
 
     rafthip_stats_t stats{};
 };
@@ -865,7 +877,8 @@ int rafthip_destroy(rafthip_engine* e) {
                     e->ack_result, e->rep_bits, e->packed,      e->rep_counts, e->rep_super, e->ack_buf,
                     e->d_rejected, e->self_mask, e->term_first, e->term_last, e->hb_commit, e->in_term,
                     e->wire_hdr, e->d_wire_counts, e->pp.rec, e->pp.ring,
-                    e->first_index, e->vote_first, e->part_a, e->part_b, e->part_words};
+                    e->first_index, e->vote_first, e->part_a, e->part_b, e->part_words,
+                    e->tick_el, e->tick_hb, e->tick_rt, e->tick_role, e->tick_flags, e->tick_action, e->d_tick_counts};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     for (void* b : e->stage_buf)
@@ -2748,6 +2761,136 @@ int rafthip_check_quorum(rafthip_engine* e) {
     // groups whose self mask was never uploaded keep no bit: every RecentActive is cleared
     if ((rc = ensure(e, e->self_mask, (size_t)e->stride * e->mbytes))) return rc;
     return tally_bits<false>(e, e->active, e->qactive, "RecentActive", e->self_mask);
+}
+
+// ---- RawNode.Tick for every group (tick.h) ---------------------------------
+
+static int ensure_tick(rafthip_engine* e) {
+    int rc;
+    if ((rc = ensure(e, e->tick_el, (size_t)e->stride * 4))) return rc;
+    if ((rc = ensure(e, e->tick_hb, (size_t)e->stride * 4))) return rc;
+    if ((rc = ensure(e, e->tick_rt, (size_t)e->stride * 4))) return rc;
+    if ((rc = ensure(e, e->tick_role, (size_t)e->stride))) return rc;
+    if ((rc = ensure(e, e->tick_flags, (size_t)e->stride))) return rc;
+    if ((rc = ensure(e, e->tick_action, (size_t)e->stride))) return rc;
+    return ensure(e, e->d_tick_counts, sizeof(u64) * kTickCountCopies * kTickCountStride);
+}
+
+int rafthip_tick_config(rafthip_engine* e, uint32_t election_tick, uint32_t heartbeat_tick, int check_quorum) {
+    if (!e) return fail(RAFTHIP_EINVAL, "engine is NULL");
+    // Config.validate, raft.go:296-302
+    if (heartbeat_tick == 0) return fail(RAFTHIP_EINVAL, "heartbeat tick must be greater than 0");
+    if (election_tick <= heartbeat_tick) return fail(RAFTHIP_EINVAL, "election tick must be greater than heartbeat tick");
+    if (election_tick > 0x7FFFFFFFu) return fail(RAFTHIP_EINVAL, "election tick %u does not fit the reference's int", election_tick);
+    e->election_timeout = election_tick;
+    e->heartbeat_timeout = heartbeat_tick;
+    e->check_quorum = check_quorum != 0;
+    return RAFTHIP_OK;
+}
+
+int rafthip_upload_tick_state(rafthip_engine* e, uint64_t first, uint64_t count, const uint32_t* election_elapsed,
+                              const uint32_t* heartbeat_elapsed, const uint32_t* randomized_timeout,
+                              const uint8_t* role, const uint8_t* flags) {
+    int rc = check_range(e, first, count);
+    if (rc) return rc;
+    DeviceGuard guard(e->device);
+    if ((rc = ensure_tick(e))) return rc;
+    const struct {
+        void* dst;
+        const void* src;
+        size_t width;
+    } rows[] = {{e->tick_el, election_elapsed, 4}, {e->tick_hb, heartbeat_elapsed, 4}, {e->tick_rt, randomized_timeout, 4},
+                {e->tick_role, role, 1},           {e->tick_flags, flags, 1}};
+    for (const auto& r : rows) {
+        if (!r.src || count == 0) continue;
+        HIP_TRY(hipMemcpyAsync(static_cast<char*>(r.dst) + first * r.width, r.src, count * r.width, hipMemcpyDefault, e->stream));
+        e->stats.bytes_uploaded += count * r.width;
+    }
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return RAFTHIP_OK;
+}
+
+int rafthip_read_tick_state(rafthip_engine* e, uint64_t first, uint64_t count, uint32_t* election_elapsed,
+                            uint32_t* heartbeat_elapsed, uint32_t* randomized_timeout, uint8_t* role, uint8_t* flags) {
+    int rc = check_range(e, first, count);
+    if (rc) return rc;
+    DeviceGuard guard(e->device);
+    if ((rc = ensure_tick(e))) return rc;
+    const struct {
+        const void* src;
+        void* dst;
+        size_t width;
+    } rows[] = {{e->tick_el, election_elapsed, 4}, {e->tick_hb, heartbeat_elapsed, 4}, {e->tick_rt, randomized_timeout, 4},
+                {e->tick_role, role, 1},           {e->tick_flags, flags, 1}};
+    for (const auto& r : rows) {
+        if (!r.dst || count == 0) continue;
+        HIP_TRY(hipMemcpyAsync(r.dst, static_cast<const char*>(r.src) + first * r.width, count * r.width, hipMemcpyDefault, e->stream));
+        e->stats.bytes_downloaded += count * r.width;
+    }
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return RAFTHIP_OK;
+}
+
+int rafthip_read_tick_actions(rafthip_engine* e, uint64_t first, uint64_t count, uint8_t* dst) {
+    int rc = check_range(e, first, count);
+    if (rc) return rc;
+    if (!dst) return fail(RAFTHIP_EINVAL, "dst is NULL");
+    DeviceGuard guard(e->device);
+    if ((rc = read_u8(e, e->tick_action, "tick actions", first, count, dst))) return rc;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return RAFTHIP_OK;
+}
+
+int rafthip_tick(rafthip_engine* e, uint64_t* counts) {
+    if (!e) return fail(RAFTHIP_EINVAL, "engine is NULL");
+    if (e->election_timeout == 0) return fail(RAFTHIP_EINVAL, "rafthip_tick_config has not been called");
+    DeviceGuard guard(e->device);
+    int rc;
+    if ((rc = ensure_tick(e))) return rc;
+    const bool uni = e->uniform && e->uniform_voters > 0;
+    if (e->check_quorum) {
+        if (!e->active) return fail(RAFTHIP_EINVAL, "RecentActive bits have not been uploaded");
+        // groups whose self mask was never uploaded keep no bit, as in rafthip_check_quorum
+        if ((rc = ensure(e, e->self_mask, (size_t)e->stride * e->mbytes))) return rc;
+        if (e->uniform && e->uniform_voters == 0 && (rc = ensure_masks(e))) return rc;
+    }
+    hipStream_t st = e->stream;
+    static_assert(kTickActions == RAFTHIP_TICK_ACTIONS && kTickActions <= kTickCountStride, "rafthip.h and tick.h disagree");
+    if (counts) HIP_TRY(hipMemsetAsync(e->d_tick_counts, 0, sizeof(u64) * kTickCountCopies * kTickCountStride, st));
+    const TickPlanes tp{e->tick_el, e->tick_hb, e->tick_rt, e->tick_role, e->tick_flags, e->tick_action};
+    const u32 blocks = (u32)((e->G + (u64)kBlock * 4 - 1) / ((u64)kBlock * 4));
+#define RAFTHIP_TK(MT)                                                                                             \
+    hipLaunchKernelGGL((k_tick<MT>), dim3(blocks), dim3(kBlock), 0, st, tp, e->G, (int)e->S, e->election_timeout,    \
+                       e->heartbeat_timeout, e->check_quorum ? 1u : 0u, static_cast<MT*>(e->active),                 \
+                       uni ? nullptr : static_cast<const MT*>(e->in_mask),                                           \
+                       uni ? nullptr : static_cast<const MT*>(e->out_mask),                                          \
+                       uni ? nullptr : static_cast<const MT*>(e->learner_mask), (int)e->uniform_voters,              \
+                       static_cast<const MT*>(e->self_mask), counts ? e->d_tick_counts : nullptr)
+    if (blocks) {
+        if (e->mbytes == 1) {
+            RAFTHIP_TK(uint8_t);
+        } else if (e->mbytes == 2) {
+            RAFTHIP_TK(uint16_t);
+        } else if (e->mbytes == 4) {
+            RAFTHIP_TK(uint32_t);
+        } else {
+            RAFTHIP_TK(uint64_t);
+        }
+    }
+#undef RAFTHIP_TK
+    HIP_TRY(hipGetLastError());
+    e->stats.groups_evaluated += e->G;
+    if (counts) {
+        u64 sets[kTickCountCopies * kTickCountStride];
+        HIP_TRY(hipMemcpyAsync(sets, e->d_tick_counts, sizeof(sets), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        for (int b = 0; b < kTickActions; ++b) {
+            u64 sum = 0;
+            for (int c = 0; c < kTickCountCopies; ++c) sum += sets[c * kTickCountStride + b];
+            counts[b] = sum;
+        }
+    }
+    return RAFTHIP_OK;
 }
 
 static int read_bits(rafthip_engine* e, const void* plane, const char* what, uint64_t first, uint64_t count,

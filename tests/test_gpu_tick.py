@@ -1,0 +1,167 @@
+"""GPU parity of K12, rafthip_tick (RawNode.Tick for every group, raft.go:823-862), through the C ABI: the tick
+loops of the reference's own tests (tests/tick_scenarios.py), then random state over every mask width, uniform and
+joint configs with learners, ragged group counts, many ticks in a row — every plane, the action bytes and the counts
+against the oracle after each tick."""
+import numpy as np
+import pytest
+
+import golden_util as gu
+import raft_amd
+import tick_scenarios as ts
+from test_gpu_parity import rand_masks
+
+pytestmark = pytest.mark.gpu
+
+
+class EngineTicker:
+    """tick_scenarios' ticker interface over one engine."""
+
+    def __init__(self, G, S, election_tick, heartbeat_tick, check_quorum, uniform_voters=0, masks=None):
+        self.e = raft_amd.Engine(G, S)
+        self.G, self.S = G, S
+        self.mdt = self.e.mask_dtype
+        if masks:
+            self.e.upload_config(*masks)
+        else:
+            self.e.set_uniform_config(uniform_voters)
+        self.e.tick_config(election_tick, heartbeat_tick, check_quorum)
+        self.e.upload_active(np.zeros(G, self.mdt))
+        self.e.upload_self(np.zeros(G, self.mdt))
+
+    def load(self, el=None, hb=None, rt=None, role=None, flags=None, active=None, self_mask=None):
+        self.e.upload_tick_state(el, hb, rt, role, flags)
+        if active is not None:
+            self.e.upload_active(np.ascontiguousarray(active, dtype=self.mdt))
+        if self_mask is not None:
+            self.e.upload_self(np.ascontiguousarray(self_mask, dtype=self.mdt))
+
+    def tick(self):
+        counts = self.e.tick()
+        act = self.e.read_tick_actions()
+        assert np.array_equal(counts, ts.counts_of(act))
+        return act, counts
+
+    def state(self):
+        return self.e.read_tick_state() + (self.e.read_active(),)
+
+    def close(self):
+        self.e.close()
+
+
+@pytest.mark.parametrize("scenario", ts.SCENARIOS, ids=lambda f: f.__name__)
+def test_reference_tick_loops_on_the_engine(scenario):
+    made = []
+
+    def mk(**kw):
+        made.append(EngineTicker(**kw))
+        return made[-1]
+    try:
+        scenario(mk)
+    finally:
+        for t in made:
+            t.close()
+
+
+@pytest.mark.parametrize("S", [1, 3, 5, 8, 9, 16, 17, 32, 33, 64])
+@pytest.mark.parametrize("config", ["uniform", "joint"])
+def test_tick_random_state_every_mask_width(oracle, S, config):
+    rng = np.random.default_rng(7000 + S + (100 if config == "joint" else 0))
+    G = [1, 5, 1023, 1025, 4097, 20000][S % 6]
+    et, ht, cq = 5, 2, True
+    mdt = gu.mask_dtype(S)
+    full = (1 << S) - 1
+
+    def bits():
+        if S < 64:
+            return rng.integers(0, full + 1, size=G, dtype=np.uint64).astype(mdt)
+        return (rng.integers(0, 1 << 63, size=G, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=G, dtype=np.uint64)).astype(mdt)
+
+    masks = None
+    V = max(1, S - 1)
+    if config == "joint":
+        m0, m1 = rand_masks(rng, S, G, joint_frac=0.5, empty_frac=0.05)
+        learners = (~(m0 | m1)) & mdt(full if S < 64 else gu.U64MAX)
+        learners = np.where(rng.random(G) < 0.5, learners, mdt(0)).astype(mdt)
+        masks = (m0, m1, learners)
+    o = ts.OracleTicker(oracle, G, S, et, ht, cq, uniform_voters=0 if masks else V, masks=masks)
+    t = EngineTicker(G, S, et, ht, cq, uniform_voters=0 if masks else V, masks=masks)
+    try:
+        self_mask = (np.uint64(1) << rng.integers(0, S, G).astype(np.uint64)).astype(mdt)
+        self_mask[::7] = 0  # a leader without a Progress row of its own
+        init = dict(el=rng.integers(0, 2 * et, G), hb=rng.integers(0, ht + 1, G), rt=rng.integers(et, 2 * et, G),
+                    role=rng.integers(0, 4, G), flags=rng.integers(0, 4, G), active=bits() & bits(), self_mask=self_mask)
+        o.load(**init)
+        t.load(**init)
+        total = np.zeros(5, dtype=np.uint64)
+        for k in range(3 * et + 1):
+            want_act, want_counts = o.tick()
+            act, counts = t.tick()
+            assert np.array_equal(act, want_act), (k, np.flatnonzero(act != want_act)[:8])
+            assert np.array_equal(counts, want_counts)
+            for name, a, b in zip(("el", "hb", "rt", "role", "flags", "active"), t.state(), o.state()):
+                assert np.array_equal(a, b), (k, name, np.flatnonzero(a != b)[:8])
+            total += counts
+            # between ticks: responses arrive (RecentActive, raft.go:1337,1528), a few followers win elections
+            a = o.state()[5] | (bits() & bits())
+            role = o.state()[3]
+            role[rng.random(G) < 0.05] = ts.LEADER
+            flags = o.state()[4] | (rng.random(G) < 0.03).astype(np.uint8) * np.uint8(ts.TRANSFER)
+            for x in (o, t):
+                x.load(active=a, role=role, flags=flags)
+        if G >= 1000:
+            assert np.all(total > 0), total  # every action occurred
+    finally:
+        t.close()
+
+
+def test_tick_without_check_quorum_needs_no_active_bits_and_counts_are_optional(oracle):
+    G, S = 3000, 3
+    rng = np.random.default_rng(7300)
+    with raft_amd.Engine(G, S) as e:
+        with pytest.raises(raft_amd.RafthipError):
+            e.tick()  # no rafthip_tick_config yet
+        for bad in ((10, 0), (1, 1), (3, 5)):  # Config.validate, raft.go:296-302
+            with pytest.raises(raft_amd.RafthipError):
+                e.tick_config(bad[0], bad[1], False)
+        e.set_uniform_config(3)
+        e.tick_config(10, 3, False)
+        role = rng.integers(0, 4, G).astype(np.uint8)
+        flags = rng.integers(0, 4, G).astype(np.uint8)
+        rt = rng.integers(10, 20, G).astype(np.uint32)
+        e.upload_tick_state(None, None, rt, role, flags)
+        o = ts.OracleTicker(oracle, G, S, 10, 3, False, uniform_voters=3)
+        o.load(rt=rt, role=role, flags=flags)
+        for k in range(25):
+            want, _ = o.tick()
+            e.tick(counts=(k % 2 == 0))
+            assert np.array_equal(e.read_tick_actions(), want), k
+        for a, b in zip(e.read_tick_state(), o.state()[:5]):
+            assert np.array_equal(a, b)
+        e.tick_config(10, 3, True)
+        with pytest.raises(raft_amd.RafthipError):
+            e.tick()  # CheckQuorum without RecentActive bits
+
+
+def test_tick_a_million_groups(oracle):
+    """2^20 groups x 9 slots (7 voters + 2 learners, cfg5's shape), steady state: every group a leader or follower
+    in a random phase of its timers, twelve ticks."""
+    G, S, V, et, ht = 1 << 20, 9, 7, 10, 1
+    rng = np.random.default_rng(7400)
+    mdt = gu.mask_dtype(S)
+    o = ts.OracleTicker(oracle, G, S, et, ht, True, uniform_voters=V)
+    t = EngineTicker(G, S, et, ht, True, uniform_voters=V)
+    try:
+        init = dict(el=rng.integers(0, et, G), hb=np.zeros(G), rt=rng.integers(et, 2 * et, G),
+                    role=np.where(rng.random(G) < 0.4, ts.LEADER, ts.FOLLOWER), flags=np.full(G, ts.PROMOTABLE),
+                    active=rng.integers(0, 1 << S, G).astype(mdt), self_mask=np.ones(G, mdt))
+        o.load(**init)
+        t.load(**init)
+        for k in range(12):
+            want_act, want_counts = o.tick()
+            counts = t.e.tick()
+            assert np.array_equal(counts, want_counts), k
+            assert np.array_equal(t.e.read_tick_actions(), want_act), k
+        for name, a, b in zip(("el", "hb", "rt", "role", "flags", "active"), t.state(), o.state()):
+            assert np.array_equal(a, b), name
+    finally:
+        t.close()

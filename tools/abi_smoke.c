@@ -253,6 +253,31 @@ int main(void) {
     OK(rafthip_check_quorum(e));
     OK(rafthip_ack_quorum(e));
     OK(rafthip_read_ack_quorum(e, FIRST, COUNT, r8));
+    /* RawNode.Tick for every group */
+    FAILS(rafthip_tick(e, NULL));                 /* rafthip_tick_config first */
+    FAILS(rafthip_tick_config(e, 10, 0, 1));      /* Config.validate, raft.go:296-302 */
+    FAILS(rafthip_tick_config(e, 2, 2, 1));
+    OK(rafthip_tick_config(e, 10, 1, 1));
+    {
+        uint32_t *el = buf(COUNT * 4), *hb = buf(COUNT * 4), *rt = buf(COUNT * 4);
+        uint8_t *role = buf(COUNT), *fl = buf(COUNT), *act = buf(COUNT);
+        uint64_t counts[RAFTHIP_TICK_ACTIONS], seen[RAFTHIP_TICK_ACTIONS] = {0};
+        for (unsigned g = 0; g < COUNT; g++) el[g] %= 20, hb[g] = 0, rt[g] = 10 + rt[g] % 10, role[g] &= 3, fl[g] &= 3;
+        OK(rafthip_upload_tick_state(e, FIRST, COUNT, el, hb, rt, role, fl));
+        OK(rafthip_upload_tick_state(e, FIRST, COUNT, NULL, NULL, NULL, role, NULL));
+        OK(rafthip_tick(e, counts));
+        OK(rafthip_tick(e, NULL));
+        OK(rafthip_tick(e, counts));
+        OK(rafthip_read_tick_actions(e, 0, G, buf(G)));
+        OK(rafthip_read_tick_actions(e, FIRST, COUNT, act));
+        for (unsigned g = 0; g < COUNT; g++)
+            for (int b = 0; b < RAFTHIP_TICK_ACTIONS; b++) seen[b] += (act[g] >> b) & 1;
+        for (int b = 0; b < RAFTHIP_TICK_ACTIONS; b++)
+            if (seen[b] != counts[b]) { fprintf(stderr, "tick count %d: %llu != %llu\n", b, (unsigned long long)counts[b], (unsigned long long)seen[b]); return 1; }
+        OK(rafthip_read_tick_state(e, FIRST, COUNT, el, hb, rt, role, fl));
+        OK(rafthip_read_tick_state(e, FIRST, COUNT, NULL, NULL, NULL, role, NULL));
+        FAILS(rafthip_read_tick_actions(e, FIRST, G, act));
+    }
     OK(rafthip_set_uniform_config(e, 7));
     OK(rafthip_commit(e));
     OK(rafthip_tally_votes(e));

@@ -208,6 +208,17 @@ def main():
         timed("k_tally_bits_small QuorumActive (K3)", "group", G, 2, e.quorum_active)
         timed("k_tally_bits_small ack quorum (K3)", "group", G, 2, e.ack_quorum)
         timed("k_tally_bits_small CheckQuorum + reset (K3)", "group", G, 4, e.check_quorum)
+        # K12, RawNode.Tick for every group (raft.go:823-862): ElectionTick 10, HeartbeatTick 1, CheckQuorum; 40 % of the
+        # groups led here, timers in a random phase.  Per group: the two elapsed counters read and written (16 B),
+        # the randomized timeout, role and flags read (6 B), the action byte written (1 B) = 23 B; RecentActive, the
+        # self mask and the config masks are only read by a wavefront that holds a group whose election timeout is up
+        e.tick_config(10, 1, True)
+        e.upload_tick_state(rng.integers(0, 10, size=G, dtype=np.uint32), np.zeros(G, dtype=np.uint32),
+                            rng.integers(10, 20, size=G, dtype=np.uint32),
+                            np.where(rng.random(G) < 0.4, 2, 0).astype(np.uint8), np.ones(G, dtype=np.uint8))
+        timed("k_tick RawNode.Tick, 40 % leaders, CheckQuorum (K12)", "group", G, 23, lambda: e.tick(counts=False))
+        e.upload_active(bits)
+        timed("k_tick + the counts read back (K12)", "group", G, 23, e.tick, iters=5)
         m0 = np.full(G, 0b11111, dtype=np.uint8)
         e.upload_config(m0, m0 >> 1, np.zeros(G, dtype=np.uint8))
         timed("k_tally_votes_small<5> masked joint (K3)", "group", G, 5 + 3 + 3, e.tally_votes)
