@@ -668,6 +668,18 @@ int rafthip_read_tick_state(rafthip_engine *e, uint64_t first, uint64_t count, u
                             uint8_t *flags);
 int rafthip_tick(rafthip_engine *e, uint64_t *counts);
 int rafthip_read_tick_actions(rafthip_engine *e, uint64_t first, uint64_t count, uint8_t *dst);
+/* The groups of the last rafthip_tick whose action byte has a bit of `mask`, in
+ * group order, with their action byte: what the host walks instead of the whole
+ * action plane (campaigns, step-downs and transfer timeouts are a handful per
+ * tick among millions of groups).  At most max_events records are written to dst
+ * (host or device memory); *n_events receives how many there are.  Engines of at
+ * most 2^32 groups.  Waits for the GPU. */
+typedef struct rafthip_tick_event {
+    uint32_t group;
+    uint32_t action; /* RAFTHIP_TICK_* bits, all of the group's, not only those of mask */
+} rafthip_tick_event;
+int rafthip_read_tick_events(rafthip_engine *e, uint32_t mask, rafthip_tick_event *dst, uint64_t max_events,
+                             uint64_t *n_events);
 
 /* ReadIndex ack quorum — Voters.VoteResult(acks) at raft.go:1552 with the
  * yes-only map of read_only.go:68-76.  Output: VoteResult per group. */

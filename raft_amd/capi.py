@@ -52,7 +52,7 @@ SYMBOLS = [
     "rafthip_commit_allgather_dense", "rafthip_commit_allgather_dense_many", "rafthip_commit_report_many",
     "rafthip_init_progress_row",
     "rafthip_tick_config", "rafthip_upload_tick_state", "rafthip_read_tick_state", "rafthip_tick",
-    "rafthip_read_tick_actions",
+    "rafthip_read_tick_actions", "rafthip_read_tick_events",
 ]
 COMM_ID_BYTES = 128
 # RawNode.Tick (rafthip.h RAFTHIP_TICK_*): StateType of raft.go:48-53, action bits, flag bits
@@ -60,6 +60,7 @@ STATE_FOLLOWER, STATE_CANDIDATE, STATE_LEADER, STATE_PRE_CANDIDATE = 0, 1, 2, 3
 TICK_HUP, TICK_CHECK_QUORUM, TICK_STEP_DOWN, TICK_ABORT_TRANSFER, TICK_BEAT = 1, 2, 4, 8, 16
 TICK_ACTIONS = 5
 TICKF_PROMOTABLE, TICKF_TRANSFER = 1, 2
+TICK_EVENT_DTYPE = np.dtype([("group", "<u4"), ("action", "<u4")])
 MSG_VOTE_RESP, MSG_PRE_VOTE_RESP = 6, 18
 
 STATE_PROBE, STATE_REPLICATE, STATE_SNAPSHOT, PROGRESS_PAUSED = 0, 1, 2, 4
@@ -175,6 +176,7 @@ def load_library():
         "rafthip_read_tick_state": (i32, [vp, u64, u64, vp, vp, vp, vp, vp]),
         "rafthip_tick": (i32, [vp, vp]),
         "rafthip_read_tick_actions": (i32, [vp, u64, u64, vp]),
+        "rafthip_read_tick_events": (i32, [vp, C.c_uint32, vp, u64, C.POINTER(u64)]),
         "rafthip_read_active": (i32, [vp, u64, u64, vp]),
         "rafthip_read_acks": (i32, [vp, u64, u64, vp]),
         "rafthip_read_term_range": (i32, [vp, u64, u64, vp, vp]),
@@ -597,6 +599,18 @@ class Engine:
         out = np.zeros(TICK_ACTIONS, dtype=np.uint64)
         _check(self._L.rafthip_tick(self._h, _ptr(out)))
         return out
+
+    def read_tick_events(self, mask, max_events=None, dst=None):
+        """(events[TICK_EVENT_DTYPE] in group order, total); with dst (device / page-locked address) only the total."""
+        if max_events is None:
+            max_events = self.G
+        n = C.c_uint64()
+        if dst is not None:
+            _check(self._L.rafthip_read_tick_events(self._h, mask, _ptr(dst) if max_events else None, max_events, C.byref(n)))
+            return n.value
+        out = np.empty(max_events, dtype=TICK_EVENT_DTYPE)
+        _check(self._L.rafthip_read_tick_events(self._h, mask, _ptr(out) if max_events else None, max_events, C.byref(n)))
+        return out[:min(n.value, max_events)], n.value
 
     def read_tick_actions(self, first=0, count=None):
         first, count = self._range(first, count)

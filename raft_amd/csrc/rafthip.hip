@@ -227,6 +227,7 @@ struct rafthip_engine {
     uint8_t* tick_flags = nullptr;  // RAFTHIP_TICKF_*
     uint8_t* tick_action = nullptr; // RAFTHIP_TICK_* of the last pass
     u64* d_tick_counts = nullptr;   // [kTickCountCopies][kTickCountStride]
+    u64* tick_ev = nullptr;         // rafthip_read_tick_events: the total, then one u32 count / offset per tile of kEvTile groups
     u32 election_timeout = 0, heartbeat_timeout = 0;  // 0: rafthip_tick_config has not been called
     bool check_quorum = false;
 
@@ -878,7 +879,7 @@ int rafthip_destroy(rafthip_engine* e) {
                     e->d_rejected, e->self_mask, e->term_first, e->term_last, e->hb_commit, e->in_term,
                     e->wire_hdr, e->d_wire_counts, e->pp.rec, e->pp.ring,
                     e->first_index, e->vote_first, e->part_a, e->part_b, e->part_words,
-                    e->tick_el, e->tick_hb, e->tick_rt, e->tick_role, e->tick_flags, e->tick_action, e->d_tick_counts};
+                    e->tick_el, e->tick_hb, e->tick_rt, e->tick_role, e->tick_flags, e->tick_action, e->d_tick_counts, e->tick_ev};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     for (void* b : e->stage_buf)
@@ -2890,6 +2891,51 @@ int rafthip_tick(rafthip_engine* e, uint64_t* counts) {
             counts[b] = sum;
         }
     }
+    return RAFTHIP_OK;
+}
+
+int rafthip_read_tick_events(rafthip_engine* e, uint32_t mask, rafthip_tick_event* dst, uint64_t max_events,
+                             uint64_t* n_events) {
+    if (!e) return fail(RAFTHIP_EINVAL, "engine is NULL");
+    if (!n_events) return fail(RAFTHIP_EINVAL, "n_events is NULL");
+    if (max_events && !dst) return fail(RAFTHIP_EINVAL, "dst is NULL");
+    if (!e->tick_action) return fail(RAFTHIP_EINVAL, "rafthip_tick has not run on this engine");
+    if (e->G > 0xFFFFFFFFull) return fail(RAFTHIP_EINVAL, "a tick event holds a 32-bit group id");
+    static_assert(sizeof(TickEvent) == sizeof(rafthip_tick_event), "rafthip.h and tick.h disagree");
+    DeviceGuard guard(e->device);
+    const u32 tiles = (u32)((e->G + kEvTile - 1) / kEvTile);
+    int rc;
+    if ((rc = ensure(e, e->tick_ev, sizeof(u64) + (size_t)tiles * sizeof(u32)))) return rc;
+    u32* tile_counts = reinterpret_cast<u32*>(e->tick_ev + 1);
+    hipStream_t st = e->stream;
+    hipLaunchKernelGGL(k_tick_event_count, dim3(tiles), dim3(kBlock), 0, st, e->tick_action, e->G, mask & 0xFFu, tile_counts);
+    hipLaunchKernelGGL(k_tick_event_scan, dim3(1), dim3(kBlock), 0, st, tile_counts, tiles, e->tick_ev);
+    HIP_TRY(hipGetLastError());
+    u64 total = 0;
+    HIP_TRY(hipMemcpyAsync(&total, e->tick_ev, sizeof(u64), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    *n_events = total;
+    const u64 take = total < max_events ? total : max_events;
+    if (take == 0) return RAFTHIP_OK;
+    // device memory and page-locked host memory are written by the kernel itself; pageable memory through a staging buffer
+    TickEvent* out = nullptr;
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, dst) == hipSuccess) {
+        if (attr.type == hipMemoryTypeDevice) out = reinterpret_cast<TickEvent*>(dst);
+        else if (attr.type == hipMemoryTypeHost && attr.devicePointer) out = static_cast<TickEvent*>(attr.devicePointer);
+    }
+    (void)hipGetLastError();
+    const bool staged = out == nullptr;
+    if (staged) {
+        if ((rc = stage_reserve(e, kStageAux, (size_t)take * sizeof(TickEvent)))) return rc;
+        out = static_cast<TickEvent*>(e->stage_buf[kStageAux]);
+    }
+    hipLaunchKernelGGL(k_tick_event_pack, dim3(tiles), dim3(kBlock), 0, st, e->tick_action, e->G, mask & 0xFFu, tile_counts,
+                       (u64)0, out, take);
+    HIP_TRY(hipGetLastError());
+    if (staged) HIP_TRY(hipMemcpyAsync(dst, out, (size_t)take * sizeof(TickEvent), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    e->stats.bytes_downloaded += take * sizeof(TickEvent);
     return RAFTHIP_OK;
 }
 

@@ -153,4 +153,99 @@ __global__ __launch_bounds__(kBlock) void k_tick(const TickPlanes t, u64 G, int 
     }
 }
 
+// ---------------------------------------------------------------------------
+// The groups of the last pass whose action byte has a bit of `mask`, as (group, action) records in group order
+// (rafthip_read_tick_events): what the host walks instead of the whole action plane — campaigns, step-downs and
+// transfer timeouts are a handful per tick among millions of groups.  Three small passes over the action bytes,
+// 16 per lane: per-workgroup counts, one workgroup scans them, then every workgroup writes its records at its
+// offset.  No atomics order the output: it is sorted by group and reproducible.
+// ---------------------------------------------------------------------------
+struct TickEvent {  // = rafthip_tick_event
+    u32 group;
+    u32 action;
+};
+constexpr int kEvPerLane = 16, kEvTile = kBlock * kEvPerLane;  // 4096 groups per workgroup: divides the plane stride
+
+__device__ __forceinline__ u32 tick_hits(const uint8_t* __restrict__ action, u64 g0, u64 G, u32 mask, Vec<u32, 4>& a) {
+    a = load_vec<u32, 4>(reinterpret_cast<const u32*>(action + g0));
+    u32 n = 0;
+#pragma unroll
+    for (int i = 0; i < kEvPerLane; ++i)
+        n += (((a.v[i >> 2] >> (8 * (i & 3))) & mask) != 0 && g0 + i < G) ? 1u : 0u;
+    return n;
+}
+
+__global__ __launch_bounds__(kBlock) void k_tick_event_count(const uint8_t* __restrict__ action, u64 G, u32 mask,
+                                                             u32* __restrict__ tile_counts) {
+    __shared__ u32 wave_tot[kBlock / 64];
+    Vec<u32, 4> a;
+    u32 n = tick_hits(action, ((u64)blockIdx.x * kBlock + threadIdx.x) * kEvPerLane, G, mask, a);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) n += __shfl_xor(n, off, 64);
+    if ((threadIdx.x & 63) == 0) wave_tot[threadIdx.x >> 6] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u32 s = 0;
+#pragma unroll
+        for (int w = 0; w < kBlock / 64; ++w) s += wave_tot[w];
+        tile_counts[blockIdx.x] = s;
+    }
+}
+
+// One workgroup: tile_counts[i] becomes the number of records in front of tile i; *total = all of them.
+__global__ __launch_bounds__(kBlock) void k_tick_event_scan(u32* __restrict__ tile_counts, u32 tiles, u64* __restrict__ total) {
+    __shared__ u32 part[kBlock];
+    const u32 per = (tiles + kBlock - 1) / kBlock, lo = threadIdx.x * per, hi = lo + per < tiles ? lo + per : tiles;
+    u32 s = 0;
+    for (u32 i = lo; i < hi; ++i) s += tile_counts[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u32 run = 0;
+        for (int i = 0; i < kBlock; ++i) {
+            const u32 v = part[i];
+            part[i] = run;
+            run += v;
+        }
+        *total = run;
+    }
+    __syncthreads();
+    u32 run = part[threadIdx.x];
+    for (u32 i = lo; i < hi; ++i) {
+        const u32 v = tile_counts[i];
+        tile_counts[i] = run;
+        run += v;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_tick_event_pack(const uint8_t* __restrict__ action, u64 G, u32 mask,
+                                                            const u32* __restrict__ tile_offsets, u64 group_base,
+                                                            TickEvent* __restrict__ out, u64 max_events) {
+    __shared__ u32 wave_tot[kBlock / 64];
+    const u64 g0 = ((u64)blockIdx.x * kBlock + threadIdx.x) * kEvPerLane;
+    Vec<u32, 4> a;
+    const u32 n = tick_hits(action, g0, G, mask, a);
+    // exclusive prefix of n over the wavefront, then over the workgroup's wavefronts
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    u32 incl = n;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const u32 v = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += v;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    u64 at = tile_offsets[blockIdx.x] + (incl - n);
+    for (int w = 0; w < wave; ++w) at += wave_tot[w];
+    if (n == 0) return;
+#pragma unroll
+    for (int i = 0; i < kEvPerLane; ++i) {
+        const u32 act = (a.v[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+        if ((act & mask) != 0 && g0 + i < G) {
+            if (at < max_events) out[at] = TickEvent{(u32)(group_base + g0 + i), act};
+            ++at;
+        }
+    }
+}
+
 }  // namespace rafthip

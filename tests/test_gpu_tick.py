@@ -48,6 +48,16 @@ class EngineTicker:
         self.e.close()
 
 
+def check_events(e, act, mask, cap=None):
+    """rafthip_read_tick_events against the action plane: the groups with a bit of `mask`, in group order, each with
+    its whole action byte; a destination shorter than the list gets the head of it and the full count."""
+    want = np.flatnonzero((act & np.uint8(mask & 0xFF)) != 0)
+    ev, n = e.read_tick_events(mask, max_events=cap)
+    assert n == len(want)
+    keep = len(want) if cap is None else min(cap, len(want))
+    assert np.array_equal(ev["group"], want[:keep]) and np.array_equal(ev["action"], act[want[:keep]])
+
+
 @pytest.mark.parametrize("scenario", ts.SCENARIOS, ids=lambda f: f.__name__)
 def test_reference_tick_loops_on_the_engine(scenario):
     made = []
@@ -101,6 +111,7 @@ def test_tick_random_state_every_mask_width(oracle, S, config):
             for name, a, b in zip(("el", "hb", "rt", "role", "flags", "active"), t.state(), o.state()):
                 assert np.array_equal(a, b), (k, name, np.flatnonzero(a != b)[:8])
             total += counts
+            check_events(t.e, act, [0xFF, ts.HUP | ts.STEP_DOWN, ts.ABORT_TRANSFER, ts.BEAT, 0][k % 5], cap=[None, 3, 0][k % 3])
             # between ticks: responses arrive (RecentActive, raft.go:1337,1528), a few followers win elections
             a = o.state()[5] | (bits() & bits())
             role = o.state()[3]
@@ -161,7 +172,19 @@ def test_tick_a_million_groups(oracle):
             counts = t.e.tick()
             assert np.array_equal(counts, want_counts), k
             assert np.array_equal(t.e.read_tick_actions(), want_act), k
+            check_events(t.e, want_act, ts.HUP | ts.STEP_DOWN | ts.ABORT_TRANSFER)
         for name, a, b in zip(("el", "hb", "rt", "role", "flags", "active"), t.state(), o.state()):
             assert np.array_equal(a, b), name
+        # the records straight into device memory and into page-locked host memory
+        import torch
+        want = np.flatnonzero((want_act & np.uint8(ts.BEAT)) != 0)
+        d = torch.zeros(2 * G, dtype=torch.int32, device="cuda")
+        assert t.e.read_tick_events(ts.BEAT, max_events=G, dst=d.data_ptr()) == len(want)
+        t.e.synchronize()
+        got = d.cpu().numpy().view(raft_amd.capi.TICK_EVENT_DTYPE)[:len(want)]
+        assert np.array_equal(got["group"], want) and np.all(got["action"] & ts.BEAT)
+        with raft_amd.PinnedArray(1000, raft_amd.capi.TICK_EVENT_DTYPE) as pin:
+            assert t.e.read_tick_events(ts.BEAT, max_events=1000, dst=pin.ctypes.data) == len(want)
+            assert np.array_equal(pin["group"], want[:1000])
     finally:
         t.close()

@@ -274,6 +274,19 @@ int main(void) {
             for (int b = 0; b < RAFTHIP_TICK_ACTIONS; b++) seen[b] += (act[g] >> b) & 1;
         for (int b = 0; b < RAFTHIP_TICK_ACTIONS; b++)
             if (seen[b] != counts[b]) { fprintf(stderr, "tick count %d: %llu != %llu\n", b, (unsigned long long)counts[b], (unsigned long long)seen[b]); return 1; }
+        {
+            rafthip_tick_event *ev = buf(G * sizeof(rafthip_tick_event));
+            uint64_t n = 0, want = 0;
+            uint8_t *all = buf(G);
+            OK(rafthip_read_tick_actions(e, 0, G, all));
+            for (unsigned g = 0; g < G; g++) want += (all[g] & (RAFTHIP_TICK_HUP | RAFTHIP_TICK_STEP_DOWN)) != 0;
+            OK(rafthip_read_tick_events(e, RAFTHIP_TICK_HUP | RAFTHIP_TICK_STEP_DOWN, ev, G, &n));
+            if (n != want) { fprintf(stderr, "tick events: %llu != %llu\n", (unsigned long long)n, (unsigned long long)want); return 1; }
+            for (uint64_t i = 0; i < n; i++)
+                if (ev[i].group >= G || ev[i].action != all[ev[i].group] || (i && ev[i].group <= ev[i - 1].group)) { fprintf(stderr, "tick event %llu is wrong\n", (unsigned long long)i); return 1; }
+            OK(rafthip_read_tick_events(e, 0xFF, NULL, 0, &n));
+            FAILS(rafthip_read_tick_events(e, 0xFF, NULL, 4, &n));
+        }
         OK(rafthip_read_tick_state(e, FIRST, COUNT, el, hb, rt, role, fl));
         OK(rafthip_read_tick_state(e, FIRST, COUNT, NULL, NULL, NULL, role, NULL));
         FAILS(rafthip_read_tick_actions(e, FIRST, G, act));
