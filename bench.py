@@ -513,6 +513,50 @@ def run_tick(raft_amd, torch, dev, local_rank, stream, reps):
                 "oracle_checked_messages": checked}
 
 
+def run_raw_tick(raft_amd, torch, dev, local_rank, stream, reps):
+    """RawNode.Tick for every group of a GPU's share of BASELINE cfg5 (2^24 groups x (7 voters + 2 learners)):
+    rafthip_tick (K12: tickElection / tickHeartbeat with the CheckQuorum step fused in, raft.go:823-862), ElectionTick
+    10, HeartbeatTick 1, CheckQuorum on, 40 % of the groups led here, timers in a random phase.  The first tick is
+    checked against the oracle on the first 2^18 groups (timers, role, flags, RecentActive, action bytes); then the
+    rare events (campaigns, step-downs, transfer timeouts) are fetched as an ordered list."""
+    from oracle import pyoracle as po
+    G, S, V, et, ht, n = 1 << 24, 9, 7, 10, 1, 1 << 18
+    rng = np.random.default_rng(0x5EED000C)
+    el = rng.integers(0, et, size=G, dtype=np.uint32)
+    hb = np.zeros(G, dtype=np.uint32)
+    rt = rng.integers(et, 2 * et, size=G, dtype=np.uint32)
+    role = np.where(rng.random(G) < 0.4, 2, 0).astype(np.uint8)
+    flags = np.ones(G, dtype=np.uint8)
+    active = rng.integers(0, 1 << S, size=G).astype(np.uint16)
+    self_mask = np.ones(G, dtype=np.uint16)
+    with raft_amd.Engine(G, S, device=local_rank, stream=stream.cuda_stream) as e:
+        e.set_uniform_config(V)
+        e.tick_config(et, ht, True)
+        e.upload_tick_state(el, hb, rt, role, flags)
+        e.upload_active(active)
+        e.upload_self(self_mask)
+        with torch.cuda.stream(stream):
+            e.tick(counts=False)
+            want = [a[:n].copy() for a in (el, hb, rt, role, flags, active)]
+            want_act = po.batch_tick(want[0], want[1], want[2], want[3], want[4], et, ht, True, S, want[5],
+                                     self_mask[:n].copy(), uniform_voters=V)
+            got = e.read_tick_state(0, n) + (e.read_active(0, n),)
+            if not (np.array_equal(e.read_tick_actions(0, n), want_act) and all(np.array_equal(a, b) for a, b in zip(got, want))):
+                raise SystemExit("bench raw tick: GPU result differs from the oracle")
+            t_tick = _timed(stream, lambda: e.tick(counts=False), reps)
+            t0 = time.perf_counter()
+            counts = e.tick()
+            rare = raft_amd.capi.TICK_HUP | raft_amd.capi.TICK_STEP_DOWN | raft_amd.capi.TICK_ABORT_TRANSFER
+            ev, n_ev = e.read_tick_events(rare, max_events=1 << 22)
+            t_ev = time.perf_counter() - t0
+        return {"groups": G, "slots": S, "election_tick": et, "heartbeat_tick": ht, "check_quorum": True,
+                "tick_ms": round(t_tick * 1e3, 4), "groups_per_s": G / t_tick, "bytes_per_group": 23,
+                "frac_of_hbm_peak": round(G * 23 / t_tick / 1e9 / HBM_PEAK_GBS, 4), "kernel": "k_tick<uint16_t>",
+                "counts_hup_checkquorum_stepdown_aborttransfer_beat": [int(c) for c in counts],
+                "tick_with_counts_and_event_list_wall_ms": round(t_ev * 1e3, 3), "events_listed": int(n_ev),
+                "oracle_checked_groups": n}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -936,6 +980,12 @@ def main():
             extra["tick_4M_groups_16M_responses"] = run_tick(raft_amd, torch, dev, local_rank, stream, 3)
         except Exception as ex:
             extra["tick_4M_groups_16M_responses"] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
+        torch.cuda.empty_cache()
+        # the caller of the CheckQuorum tally and the heartbeat fan-out: RawNode.Tick for every group
+        try:
+            extra["raw_node_tick_16M_groups"] = run_raw_tick(raft_amd, torch, dev, local_rank, stream, 10)
+        except Exception as ex:
+            extra["raw_node_tick_16M_groups"] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
         torch.cuda.empty_cache()
 
     if rank == 0:
