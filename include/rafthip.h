@@ -642,7 +642,8 @@ int rafthip_check_quorum(rafthip_engine *e);
  *                                the transfer flag and every RecentActive bit cleared
  *                                (becomeFollower -> reset, raft.go:864-871,760-789); the host does the
  *                                rest of reset: a new randomized timeout, rafthip_reset_match,
- *                                rafthip_reset_votes, the Progress rows
+ *                                rafthip_reset_votes, the Progress rows, and clears the group's self
+ *                                mask (rafthip_upload_self: the group is no longer led here)
  *   RAFTHIP_TICK_ABORT_TRANSFER  a leader's transfer did not finish within an election timeout
  *                                (raft.go:846-849); the flag is cleared
  *   RAFTHIP_TICK_BEAT            heartbeat_elapsed reached HeartbeatTick on a (still) leader: the host
