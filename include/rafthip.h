@@ -628,7 +628,7 @@ int rafthip_check_quorum(rafthip_engine *e);
  *   flags                                 RAFTHIP_TICKF_PROMOTABLE = r.promotable() (raft.go:1883-1886),
  *                                         RAFTHIP_TICKF_TRANSFER = r.leadTransferee != None
  * and for the engine ElectionTick, HeartbeatTick, CheckQuorum of raft.Config
- * (raft.go:128-138,219-224; refused as Config.validate refuses them, raft.go:296-302).
+ * (raft.go:128-138,222-224; refused as Config.validate refuses them, raft.go:296-302).
  * Counters are uint32 where the reference has int: keep them below 2^31.
  *
  * One pass advances every group by one tick and leaves an action byte per group:

@@ -164,6 +164,58 @@ func (b *BatchEngine) CheckQuorum(active []uint8) error {
 	return guarded(func() C.int { return C.rafthip_read_quorum_active(b.e, 0, C.uint64_t(len(active)), (*C.uint8_t)(unsafe.Pointer(&active[0]))) })
 }
 
+// Tick actions and state flags (rafthip.h RAFTHIP_TICK_*, RAFTHIP_TICKF_*).
+const (
+	TickHup           = 1  // tickElection fired: r.Step(MsgHup), raft.go:826-831
+	TickCheckQuorum   = 2  // MsgCheckQuorum has been stepped on the device, raft.go:1231-1243
+	TickStepDown      = 4  // ... and the quorum was not active: the rest of becomeFollower -> reset is the host's
+	TickAbortTransfer = 8  // raft.go:846-849
+	TickBeat          = 16 // r.Step(MsgBeat): bcastHeartbeat, raft.go:856-861
+	TickPromotable    = 1  // r.promotable(), raft.go:1883-1886
+	TickTransfer      = 2  // r.leadTransferee != None
+)
+
+// TickEvent is one group of the last Tick with one of the actions asked for.
+type TickEvent struct {
+	Group  uint32
+	Action uint32
+}
+
+// SetTickConfig: ElectionTick, HeartbeatTick, CheckQuorum of raft.Config for every group (raft.go:128-138,222-224;
+// refused as Config.validate refuses them, raft.go:296-302).
+func (b *BatchEngine) SetTickConfig(electionTick, heartbeatTick int, checkQuorum bool) error {
+	cq := C.int(0)
+	if checkQuorum {
+		cq = 1
+	}
+	return guarded(func() C.int { return C.rafthip_tick_config(b.e, C.uint32_t(electionTick), C.uint32_t(heartbeatTick), cq) })
+}
+
+// SetTickState: what reset / becomeLeader / becomeFollower / a leadership transfer leave in group g:
+// r.electionElapsed, r.heartbeatElapsed, r.randomizedElectionTimeout, r.state and the two flags.
+func (b *BatchEngine) SetTickState(g uint64, electionElapsed, heartbeatElapsed, randomizedTimeout uint32, state uint8, flags uint8) error {
+	return guarded(func() C.int {
+		return C.rafthip_upload_tick_state(b.e, C.uint64_t(g), 1, (*C.uint32_t)(&electionElapsed), (*C.uint32_t)(&heartbeatElapsed),
+			(*C.uint32_t)(&randomizedTimeout), (*C.uint8_t)(&state), (*C.uint8_t)(&flags))
+	})
+}
+
+// Tick: RawNode.Tick for every group (rawnode.go:64-66 -> tickElection / tickHeartbeat, raft.go:823-862) in one
+// pass.  counts[i] = groups whose action has bit i (Hup, CheckQuorum, StepDown, AbortTransfer, Beat); events receives
+// the groups with an action of mask, in group order, and the call returns how many there are.
+func (b *BatchEngine) Tick(mask uint32, events []TickEvent, counts *[5]uint64) (int, error) {
+	if err := guarded(func() C.int { return C.rafthip_tick(b.e, (*C.uint64_t)(unsafe.Pointer(&counts[0]))) }); err != nil {
+		return 0, err
+	}
+	var n C.uint64_t
+	var p *C.rafthip_tick_event
+	if len(events) > 0 {
+		p = (*C.rafthip_tick_event)(unsafe.Pointer(&events[0]))
+	}
+	err := guarded(func() C.int { return C.rafthip_read_tick_events(b.e, C.uint32_t(mask), p, C.uint64_t(len(events)), &n) })
+	return int(n), err
+}
+
 // HeartbeatCommit: sendHeartbeat's commit per peer (raft.go:669-685), [slot][group].
 func (b *BatchEngine) HeartbeatCommit(dst []uint64) error {
 	return guarded(func() C.int { return C.rafthip_heartbeat_commit(b.e, 0, C.uint64_t(b.groups), (*C.uint64_t)(unsafe.Pointer(&dst[0])),

@@ -224,6 +224,17 @@ int main() {
                     for (uint8_t x : a) putchar('0' + x);
                     printf("\n");
                 }
+            } else if (cmd == "tickconfig") {
+                rc = trk->SetTickConfig((uint32_t)u(1), (uint32_t)u(2), u(3) != 0);
+            } else if (cmd == "tickstate") {  // group el hb rt state promotable transferring
+                rc = trk->SetTickState(u(1), (uint32_t)u(2), (uint32_t)u(3), (uint32_t)u(4), (int)u(5), u(6) != 0, u(7) != 0);
+            } else if (cmd == "tick") {  // event mask
+                std::vector<tracker::BatchProgressTracker::TickEvent> ev;
+                uint64_t c[5];
+                if (!(rc = trk->Tick((uint32_t)u(1), &ev, c))) {
+                    for (const auto& x : ev) printf("tickevent %u %u\n", x.group, x.action);
+                    printf("tick %" PRIu64 " %" PRIu64 " %" PRIu64 " %" PRIu64 " %" PRIu64 "\n", c[0], c[1], c[2], c[3], c[4]);
+                }
             } else if (cmd == "progress") {
                 rc = trk->EnableProgress((uint32_t)u(1), u(2));
             } else if (cmd == "firstindex") {

@@ -483,10 +483,8 @@ int BatchProgressTracker::MaybeCommit(std::vector<CommitPair>* advanced) {
     return RAFTHIP_OK;
 }
 
-int BatchProgressTracker::CheckQuorum(std::vector<uint8_t>* active) {
-    if (!active) return fail(RAFTHIP_EINVAL, "active is NULL");
-    int rc = Flush();  // queued responses set RecentActive on the device too; same bits as the shadow
-    if (rc) return rc;
+int BatchProgressTracker::SyncActiveAndSelf() {
+    int rc;
     if (active_dirty_[0] <= active_dirty_[1]) {
         const uint64_t first = active_dirty_[0], count = active_dirty_[1] - active_dirty_[0] + 1;
         if ((rc = lib(rafthip_upload_active(e_, first, count, active_.data() + first * mb_)))) return rc;
@@ -499,6 +497,62 @@ int BatchProgressTracker::CheckQuorum(std::vector<uint8_t>* active) {
         self_dirty_[0] = 1;
         self_dirty_[1] = 0;
     }
+    return RAFTHIP_OK;
+}
+
+int BatchProgressTracker::SetTickConfig(uint32_t election_tick, uint32_t heartbeat_tick, bool check_quorum) {
+    return lib(rafthip_tick_config(e_, election_tick, heartbeat_tick, check_quorum ? 1 : 0));
+}
+
+int BatchProgressTracker::SetTickState(uint64_t group, uint32_t election_elapsed, uint32_t heartbeat_elapsed,
+                                       uint32_t randomized_timeout, int state, bool promotable, bool transferring) {
+    if (group >= G_) return fail(RAFTHIP_ERANGE, "group %llu outside [0, %llu)", (unsigned long long)group,
+                                 (unsigned long long)G_);
+    if (state < 0 || state > 3) return fail(RAFTHIP_EINVAL, "state %d is no StateType", state);
+    const uint8_t role = (uint8_t)state;
+    const uint8_t flags = (uint8_t)((promotable ? RAFTHIP_TICKF_PROMOTABLE : 0u) | (transferring ? RAFTHIP_TICKF_TRANSFER : 0u));
+    return lib(rafthip_upload_tick_state(e_, group, 1, &election_elapsed, &heartbeat_elapsed, &randomized_timeout, &role, &flags));
+}
+
+int BatchProgressTracker::Tick(uint32_t event_mask, std::vector<TickEvent>* events, uint64_t counts[5]) {
+    int rc = Flush();  // queued responses set RecentActive before the tick looks at it
+    if (rc) return rc;
+    if ((rc = SyncActiveAndSelf())) return rc;
+    uint64_t c[RAFTHIP_TICK_ACTIONS] = {0, 0, 0, 0, 0};
+    if ((rc = lib(rafthip_tick(e_, c)))) return rc;
+    if (counts) memcpy(counts, c, sizeof(c));
+    // the groups that ran MsgCheckQuorum: their RecentActive was reset on the device, the shadow follows
+    // (raft.go:1236-1242; after a step-down every bit is clear and the group is not led here any more)
+    const uint32_t mask = (event_mask | RAFTHIP_TICK_CHECK_QUORUM) & 0xFFu;
+    uint64_t cap = 0;
+    for (int b = 0; b < RAFTHIP_TICK_ACTIONS; ++b)
+        if ((mask >> b) & 1u) cap += c[b];
+    if (cap > G_) cap = G_;
+    std::vector<rafthip_tick_event> ev(cap);
+    uint64_t n = 0;
+    if ((rc = lib(rafthip_read_tick_events(e_, mask, ev.data(), cap, &n)))) return rc;
+    if (n > cap) return fail(RAFTHIP_EIO, "tick events: %llu listed, at most %llu counted", (unsigned long long)n,
+                             (unsigned long long)cap);
+    if (events) events->clear();
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint64_t g = ev[i].group;
+        if (ev[i].action & RAFTHIP_TICK_STEP_DOWN) {
+            put_mask(active_, g, 0);
+            put_mask(self_, g, 0);
+            touch(self_dirty_, g);  // the engine keeps the self mask: cleared with the next sync
+        } else if (ev[i].action & RAFTHIP_TICK_CHECK_QUORUM) {
+            put_mask(active_, g, get_mask(active_, g) & get_mask(self_, g));
+        }
+        if (events && (ev[i].action & event_mask)) events->push_back(TickEvent{ev[i].group, ev[i].action});
+    }
+    return RAFTHIP_OK;
+}
+
+int BatchProgressTracker::CheckQuorum(std::vector<uint8_t>* active) {
+    if (!active) return fail(RAFTHIP_EINVAL, "active is NULL");
+    int rc = Flush();  // queued responses set RecentActive on the device too; same bits as the shadow
+    if (rc) return rc;
+    if ((rc = SyncActiveAndSelf())) return rc;
     if ((rc = lib(rafthip_check_quorum(e_)))) return rc;
     active->assign(G_, 0);
     if ((rc = lib(rafthip_read_quorum_active(e_, 0, G_, active->data())))) return rc;

@@ -116,6 +116,23 @@ class BatchProgressTracker {
     // The MsgCheckQuorum step for every group (raft.go:1231-1243): verdicts as
     // QuorumActive(), then RecentActive = false for all but each group's self.
     int CheckQuorum(std::vector<uint8_t>* active);
+    // RawNode.Tick for every group (rawnode.go:64-66 -> tickElection / tickHeartbeat, raft.go:823-862).
+    // SetTickConfig: ElectionTick, HeartbeatTick, CheckQuorum of raft.Config (validated as raft.go:296-302).
+    // SetTickState: what reset / becomeLeader / becomeFollower / a transfer leave in one group — electionElapsed,
+    // heartbeatElapsed, randomizedElectionTimeout (drawn by the caller, raft.go:1988-1990), r.state (StateType,
+    // raft.go:48-53), promotable() (raft.go:1883-1886) and leadTransferee != None.
+    // Tick: one tick for all groups.  counts[5]: groups that stepped MsgHup, ran MsgCheckQuorum, stepped down,
+    // timed a transfer out, stepped MsgBeat.  *events (may be NULL): the groups with an action of `event_mask`
+    // (RAFTHIP_TICK_*), in group order.  MsgCheckQuorum is done for the groups it was due for, RecentActive reset
+    // included (the shadow follows); a group that stepped down is no longer led here (as SetFollower).
+    struct TickEvent {
+        uint32_t group;
+        uint32_t action;
+    };
+    int SetTickConfig(uint32_t election_tick, uint32_t heartbeat_tick, bool check_quorum);
+    int SetTickState(uint64_t group, uint32_t election_elapsed, uint32_t heartbeat_elapsed, uint32_t randomized_timeout,
+                     int state, bool promotable, bool transferring);
+    int Tick(uint32_t event_mask, std::vector<TickEvent>* events, uint64_t counts[5]);
     // sendHeartbeat's commit for peer `id` (raft.go:669-685), after MaybeCommit().
     int HeartbeatCommit(uint64_t group, uint64_t id, uint64_t* commit);
 
@@ -202,6 +219,7 @@ class BatchProgressTracker {
     uint64_t max_inflight_bytes_ = 0;
     std::vector<uint8_t> self_;      // [G] masks: the leader's own slot
     uint64_t self_dirty_[2] = {1, 0};
+    int SyncActiveAndSelf();  // dirty ranges of the two shadows to the engine
     std::vector<CommitPair> pairs_;  // landing buffer of Committed(), G entries
     // Votes is keyed by id, not by Progress (tracker/tracker.go:122,260-265):
     // votes of ids that hold no slot right now wait here until ResetVotes.

@@ -384,6 +384,79 @@ def test_tracker_leader_tick(oracle, S, G, seed):
 
 
 @pytest.mark.gpu
+def test_tracker_raw_node_tick(oracle):
+    """RawNode.Tick for every group through the host mirror (SetTickConfig / SetTickState / Tick): tickElection and
+    tickHeartbeat (raft.go:823-862) with MsgCheckQuorum and its RecentActive reset (raft.go:1231-1243), heartbeat
+    responses stepped in between the ticks — events, counts and the RecentActive state the next CheckQuorum would
+    see, against the id-keyed model stepped in the reference's statement order."""
+    import tick_scenarios as ts
+    from test_tick_oracle import py_tick
+    rng = np.random.default_rng(4242)
+    G, S, et, ht = 48, 5, 4, 2
+    pool = np.arange(1, S + 3)
+    m = Model(G)
+    st = []  # per group: [el, hb, rt, role, flags, self_id]
+    script, want = ["tracker %d %d" % (G, S), "tickconfig %d %d 1" % (et, ht)], ["tracker ok"]
+    for g in range(G):
+        inc, out, lrn = rand_config(rng, S, pool)
+        m.set_config(g, inc, out, lrn)
+        script.append("setconfig %d in=%s out=%s learners=%s" % (g, ids(inc), ids(out), ids(lrn)))
+        for i in m.active[g]:
+            m.active[g][i] = False
+            script.append("active %d %d 0" % (g, i))
+        role = ts.LEADER if rng.random() < 0.6 else int(rng.choice([ts.FOLLOWER, ts.CANDIDATE, ts.PRE_CANDIDATE]))
+        self_id = None
+        if role == ts.LEADER:
+            self_id = int(rng.choice(sorted(inc | out))) if rng.random() < 0.9 else 99
+            script.append("leader %d %d 1 10" % (g, self_id))
+            if self_id in m.active[g]:
+                m.active[g][self_id] = True
+        else:
+            script.append("follower %d" % g)
+        flags = (ts.PROMOTABLE if rng.random() < 0.8 else 0) | (ts.TRANSFER if role == ts.LEADER and rng.random() < 0.3 else 0)
+        st.append([int(rng.integers(0, et)), int(rng.integers(0, ht)), int(rng.integers(et, 2 * et)), role, flags, self_id])
+        script.append("tickstate %d %d %d %d %d %d %d" % (g, st[g][0], st[g][1], st[g][2], role, flags & 1, (flags >> 1) & 1))
+    mask = ts.HUP | ts.STEP_DOWN | ts.ABORT_TRANSFER
+    seen = 0
+    for rnd in range(3 * et):
+        for _ in range(2 * G):  # heartbeat responses: RecentActive (raft.go:1528)
+            g, i = int(rng.integers(0, G)), int(rng.choice(pool))
+            script.append("step %d %d 9 0 0 0" % (g, i))
+            if i not in m.match[g]:
+                want.append("dropped")
+            else:
+                m.active[g][i] = True
+        script.append("tick %d" % mask)
+        counts = [0] * 5
+        for g in range(G):
+            el, hb, rt, role, flags, self_id = st[g]
+            el, hb, role2, flags, _, act = py_tick(el, hb, rt, role, flags, et, ht, True, 1, 1, bool(m.quorum_active(oracle, g)))
+            if act & ts.STEP_DOWN:
+                for i in m.active[g]:
+                    m.active[g][i] = False
+                self_id = None
+            elif act & ts.CHECK_QUORUM:
+                for i in m.active[g]:
+                    if i != self_id:
+                        m.active[g][i] = False
+            st[g] = [el, hb, rt, role2, flags, self_id]
+            for b in range(5):
+                counts[b] += (act >> b) & 1
+            if act & mask:
+                want.append("tickevent %d %d" % (g, act))
+        seen |= sum(1 << b for b in range(5) if counts[b])
+        want.append("tick " + " ".join(str(c) for c in counts))
+        if rnd % 4 == 3:
+            script.append("quorumactive")
+            want.append("quorumactive " + "".join(str(m.quorum_active(oracle, g)) for g in range(G)))
+    assert seen == 31, seen  # every action occurred
+    out = run_cli("\n".join(script) + "\n", timeout=300)
+    for k, (a, b) in enumerate(zip(out, want)):
+        assert a == b, (k, a, b)
+    assert len(out) == len(want)
+
+
+@pytest.mark.gpu
 def test_tracker_progress_scenarios():
     """The reference's Progress / Inflights scenarios (tests/golden/progress.json) through
     the C++ mirror: peer 2 of a three-voter group, one flush per event and the state /
