@@ -74,7 +74,37 @@ def test_random_call_sequences(oracle, S, G, seed):
         e.upload_term(wire["term"])
         e.upload_read_ctx(wire["cw"], wire["cl"])
         e.upload_campaign(wire["camp"])
+        # RawNode.Tick (K12) shares RecentActive, the self masks and the config with the calls above.  It is driven
+        # from a generator of its own, so the sequences the seeds above produce stay what they were.
+        rng2 = np.random.default_rng(77000 + seed)
+        tk = dict(el=np.zeros(G, np.uint32), hb=np.zeros(G, np.uint32), rt=np.zeros(G, np.uint32),
+                  role=np.zeros(G, np.uint8), flags=np.zeros(G, np.uint8))
+        e.tick_config(4, 2, True)
+        ticks = 0
         for step in range(170):
+            if step % 5 == 4:
+                if rng2.random() < 0.4:  # reset / becomeLeader / a transfer on a range of groups
+                    b = int(rng2.integers(0, G))
+                    k = int(rng2.integers(0, G - b + 1))
+                    part = dict(el=rng2.integers(0, 8, k), hb=rng2.integers(0, 3, k), rt=rng2.integers(4, 8, k),
+                                role=rng2.integers(0, 4, k), flags=rng2.integers(0, 4, k))
+                    for key in tk:
+                        tk[key][b:b + k] = part[key]
+                    e.upload_tick_state(tk["el"][b:b + k], tk["hb"][b:b + k], tk["rt"][b:b + k], tk["role"][b:b + k],
+                                        tk["flags"][b:b + k], first=b, count=k)
+                else:
+                    want = po.batch_tick(tk["el"], tk["hb"], tk["rt"], tk["role"], tk["flags"], 4, 2, True, S, sh["active"],
+                                         sh["self"], **lrn_kw())
+                    counts = e.tick()
+                    act = e.read_tick_actions()
+                    assert np.array_equal(act, want), (step, np.flatnonzero(act != want)[:8])
+                    assert np.array_equal(counts, [np.count_nonzero(want & (1 << b)) for b in range(5)]), step
+                    for got, key in zip(e.read_tick_state(), ("el", "hb", "rt", "role", "flags")):
+                        assert np.array_equal(got, tk[key]), (step, key)
+                    assert np.array_equal(e.read_active(), sh["active"]), step
+                    ev, n_ev = e.read_tick_events(0xFF)
+                    assert n_ev == np.count_nonzero(want) and np.array_equal(ev["group"], np.flatnonzero(want)), step
+                    ticks += 1
             op = int(rng.integers(0, 26))
             checked[0] += 10 <= op < 16
             a, n = rng_range()
@@ -283,6 +313,7 @@ def test_random_call_sequences(oracle, S, G, seed):
                 assert np.array_equal(e.read_quorum_active(a, n), want[a:a + n]), step
                 assert np.array_equal(e.read_active(), sh["active"]), step
         assert checked[0] >= (25 if os.environ.get("RAFTHIP_FUZZ_ROUND", "0") == "0" else 10)  # the committed seeds check at least 25 calls each
+        assert ticks >= 10
         assert np.array_equal(e.read_match(), sh["match"])
         assert np.array_equal(e.read_acks(), sh["acks"])
         assert np.array_equal(e.read_term_range()[1], sh["tl"])
