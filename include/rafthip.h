@@ -581,6 +581,13 @@ int rafthip_commit_changed_static(rafthip_engine *e, rafthip_commit_pair *dst, u
 #define RAFTHIP_HEARTBEAT_STRIDE 72
 int rafthip_emit_heartbeats(rafthip_engine *e, uint64_t first, uint64_t count, uint8_t *out_bytes,
                             uint8_t *out_len);
+/* The same for the groups of the range that stepped MsgBeat in the last
+ * rafthip_tick (tickHeartbeat, raft.go:856-861 -> stepLeader MsgBeat,
+ * raft.go:1228-1230 -> bcastHeartbeat): every other group gets length 0, as a
+ * group that is not led here does.  With HeartbeatTick 1 every led group beats
+ * every tick and the two calls agree. */
+int rafthip_emit_heartbeats_due(rafthip_engine *e, uint64_t first, uint64_t count, uint8_t *out_bytes,
+                                uint8_t *out_len);
 
 
 /* raft.committedEntryInCurrentTerm for every group — raft.go:2001-2005: has the

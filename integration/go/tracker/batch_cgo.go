@@ -216,6 +216,12 @@ func (b *BatchEngine) Tick(mask uint32, events []TickEvent, counts *[5]uint64) (
 	return int(n), err
 }
 
+// HeartbeatsDue: Heartbeats for the groups that stepped MsgBeat in the last Tick only (raft.go:856-861).
+func (b *BatchEngine) HeartbeatsDue(bytes, lens []uint8) error {
+	return guarded(func() C.int { return C.rafthip_emit_heartbeats_due(b.e, 0, C.uint64_t(b.groups), (*C.uint8_t)(unsafe.Pointer(&bytes[0])),
+		(*C.uint8_t)(unsafe.Pointer(&lens[0]))) })
+}
+
 // HeartbeatCommit: sendHeartbeat's commit per peer (raft.go:669-685), [slot][group].
 func (b *BatchEngine) HeartbeatCommit(dst []uint64) error {
 	return guarded(func() C.int { return C.rafthip_heartbeat_commit(b.e, 0, C.uint64_t(b.groups), (*C.uint64_t)(unsafe.Pointer(&dst[0])),

@@ -52,7 +52,7 @@ SYMBOLS = [
     "rafthip_commit_allgather_dense", "rafthip_commit_allgather_dense_many", "rafthip_commit_report_many",
     "rafthip_init_progress_row",
     "rafthip_tick_config", "rafthip_upload_tick_state", "rafthip_read_tick_state", "rafthip_tick",
-    "rafthip_read_tick_actions", "rafthip_read_tick_events",
+    "rafthip_read_tick_actions", "rafthip_read_tick_events", "rafthip_emit_heartbeats_due",
 ]
 COMM_ID_BYTES = 128
 # RawNode.Tick (rafthip.h RAFTHIP_TICK_*): StateType of raft.go:48-53, action bits, flag bits
@@ -187,6 +187,7 @@ def load_library():
         "rafthip_upload_read_ctx": (i32, [vp, u64, u64, vp, vp]),
         "rafthip_upload_campaign": (i32, [vp, u64, u64, vp]),
         "rafthip_emit_heartbeats": (i32, [vp, u64, u64, vp, vp]),
+        "rafthip_emit_heartbeats_due": (i32, [vp, u64, u64, vp, vp]),
         "rafthip_plan_appends": (i32, [vp, u64, u64, i32, vp, vp, u64]),
         "rafthip_ingest_wire": (i32, [vp, vp, vp, vp, u64, vp, vp, vp]),
         "rafthip_progress_config": (i32, [vp, u32, u64]),
@@ -542,12 +543,14 @@ class Engine:
         _check(self._L.rafthip_plan_appends(self._h, first, count, int(bool(send_if_empty)), _ptr(plan), _ptr(nxt), count))
         return plan, nxt
 
-    def emit_heartbeats(self, first=0, count=None):
-        """bcastHeartbeat as bytes -> (uint8 [S][count][HEARTBEAT_STRIDE] zero-padded messages, uint8 [S][count] lengths)."""
+    def emit_heartbeats(self, first=0, count=None, due=False):
+        """bcastHeartbeat as bytes -> (uint8 [S][count][HEARTBEAT_STRIDE] zero-padded messages, uint8 [S][count] lengths).
+        due: only for the groups that stepped MsgBeat in the last tick (rafthip_emit_heartbeats_due)."""
         first, count = self._range(first, count)
         out = np.empty((self.S, count, HEARTBEAT_STRIDE), dtype=np.uint8)
         lens = np.empty((self.S, count), dtype=np.uint8)
-        _check(self._L.rafthip_emit_heartbeats(self._h, first, count, _ptr(out), _ptr(lens)))
+        fn = self._L.rafthip_emit_heartbeats_due if due else self._L.rafthip_emit_heartbeats
+        _check(fn(self._h, first, count, _ptr(out), _ptr(lens)))
         return out, lens
 
     def committed_in_term(self, first=0, count=None):

@@ -2610,9 +2610,20 @@ int rafthip_heartbeat_commit(rafthip_engine* e, uint64_t first, uint64_t count, 
 static_assert(kHeartbeatStride == RAFTHIP_HEARTBEAT_STRIDE, "heartbeat stride");
 static_assert(kStaticMaxGroups == RAFTHIP_STATIC_MAX_GROUPS, "static scratch limit");
 
+static int emit_heartbeats(rafthip_engine* e, uint64_t first, uint64_t count, uint8_t* out_bytes, uint8_t* out_len, bool due);
+
 int rafthip_emit_heartbeats(rafthip_engine* e, uint64_t first, uint64_t count, uint8_t* out_bytes, uint8_t* out_len) {
+    return emit_heartbeats(e, first, count, out_bytes, out_len, false);
+}
+
+int rafthip_emit_heartbeats_due(rafthip_engine* e, uint64_t first, uint64_t count, uint8_t* out_bytes, uint8_t* out_len) {
+    return emit_heartbeats(e, first, count, out_bytes, out_len, true);
+}
+
+static int emit_heartbeats(rafthip_engine* e, uint64_t first, uint64_t count, uint8_t* out_bytes, uint8_t* out_len, bool due) {
     int rc = check_range(e, first, count);
     if (rc) return rc;
+    if (due && !e->tick_action) return fail(RAFTHIP_EINVAL, "rafthip_tick has not run on this engine");
     if (!out_bytes || !out_len) return fail(RAFTHIP_EINVAL, "out_bytes/out_len is NULL");
     if (!e->have_ids || !e->have_term)
         return fail(RAFTHIP_EINVAL, "rafthip_upload_ids and rafthip_upload_term must come first");
@@ -2637,7 +2648,7 @@ int rafthip_emit_heartbeats(rafthip_engine* e, uint64_t first, uint64_t count, u
 #define RAFTHIP_EMIT(MT)                                                                                        \
     hipLaunchKernelGGL((k_emit_heartbeats<MT>), dim3(blocks), dim3(kBlock), 0, e->stream, e->match, e->stride,   \
                        e->commit, static_cast<const u64*>(e->wire_hdr), H, static_cast<const MT*>(e->self_mask), \
-                       (u64)first, (u64)count, e->S, d_bytes, d_len)
+                       (u64)first, (u64)count, e->S, d_bytes, d_len, due ? e->tick_action : nullptr)
     if (e->mbytes == 1) {
         RAFTHIP_EMIT(uint8_t);
     } else if (e->mbytes == 2) {

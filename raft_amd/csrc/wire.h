@@ -437,7 +437,8 @@ template <class MaskT>
 __global__ __launch_bounds__(kBlock) void k_emit_heartbeats(
     const u64* __restrict__ match, u64 stride, const u64* __restrict__ commit, const u64* __restrict__ hdr, u32 H,
     const MaskT* __restrict__ self_mask, u64 first, u64 count, u32 S, uint8_t* __restrict__ out_bytes /* [S][count][72] */,
-    uint8_t* __restrict__ out_len /* [S][count] */) {
+    uint8_t* __restrict__ out_len /* [S][count] */,
+    const uint8_t* __restrict__ beat /* NULL, or the action bytes of the last rafthip_tick: only groups that stepped MsgBeat */) {
     constexpr u32 W = kHeartbeatStride / 8;
     __shared__ __align__(16) u64 sm2[2][kBlock * W];  // two buffers: one barrier per slot
     const u64 g0 = (u64)blockIdx.x * kBlock;
@@ -449,7 +450,7 @@ __global__ __launch_bounds__(kBlock) void k_emit_heartbeats(
     u32 ctx_len = 0, self_slot = kWireNoSlot;
     if (live) {
         const u64 self = (u64)self_mask[g];
-        if (self != 0) {
+        if (self != 0 && (!beat || (beat[g] & 16u /* RAFTHIP_TICK_BEAT */))) {
             self_slot = (u32)__ffsll((unsigned long long)self) - 1;
             if (self_slot < S) from = row[kHdrIds + self_slot];
             term = row[kHdrTerm];

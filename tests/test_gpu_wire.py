@@ -499,6 +499,20 @@ def test_emit_heartbeats(oracle, S, G):
             assert L.rafthip_emit_heartbeats(e._h, 0, G, db.data_ptr(), dl.data_ptr()) == 0
             e.synchronize()
             assert np.array_equal(db.cpu().numpy(), want) and np.array_equal(dl.cpu().numpy(), want_len)
+            # rafthip_emit_heartbeats_due: HeartbeatTick 3, every group a leader somewhere in its heartbeat interval —
+            # only the groups whose tick stepped MsgBeat (raft.go:856-861) send, the rest read as groups not led here
+            with pytest.raises(raft_amd.RafthipError):
+                e.emit_heartbeats(due=True)  # no tick yet
+            e.tick_config(10, 3, False)
+            hb = rng.integers(0, 3, size=G).astype(np.uint32)
+            e.upload_tick_state(np.zeros(G, np.uint32), hb, np.full(G, 10, np.uint32), np.full(G, 2, np.uint8), np.ones(G, np.uint8))
+            for k in range(3):
+                e.tick(counts=False)
+                beat = (hb + k + 1) % 3 == 0
+                assert np.array_equal((e.read_tick_actions() & capi.TICK_BEAT) != 0, beat)
+                got, got_len = e.emit_heartbeats(due=True)
+                assert np.array_equal(got_len, want_len * beat[None, :]) and np.array_equal(got, want * beat[None, :, None])
+                assert beat.any() and not beat.all()
 
 
 def test_emit_heartbeats_on_the_reference_cases():

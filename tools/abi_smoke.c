@@ -289,6 +289,12 @@ int main(void) {
         }
         OK(rafthip_read_tick_state(e, FIRST, COUNT, el, hb, rt, role, fl));
         OK(rafthip_read_tick_state(e, FIRST, COUNT, NULL, NULL, NULL, role, NULL));
+        {
+            uint8_t *hb2 = buf((size_t)S * COUNT * RAFTHIP_HEARTBEAT_STRIDE), *hlen2 = buf((size_t)S * COUNT);
+            OK(rafthip_emit_heartbeats_due(e, FIRST, COUNT, hb2, hlen2));
+            for (size_t i = 0; i < (size_t)S * COUNT; i++)
+                if (hlen2[i] && !(act[i % COUNT] & RAFTHIP_TICK_BEAT)) { fprintf(stderr, "heartbeat from a group that did not beat\n"); return 1; }
+        }
         FAILS(rafthip_read_tick_actions(e, FIRST, G, act));
     }
     OK(rafthip_set_uniform_config(e, 7));
