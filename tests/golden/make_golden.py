@@ -590,6 +590,85 @@ def confchange_init_progress():
     return out
 
 
+TICK_TRANSCRIPTS = ["checkquorum.txt", "heartbeat_resp_recovers_from_probing.txt", "forget_leader.txt",
+                    "forget_leader_prevote_checkquorum.txt", "replicate_pause.txt", "snapshot_succeed_via_app_resp.txt",
+                    "slow_follower_after_compaction.txt", "confchange_v1_remove_leader.txt"]
+TICK_CMD = re.compile(r"^tick-(election|heartbeat) (\d+)\s*$")
+ADD_NODES = re.compile(r"^add-nodes (\d+)(.*)$")
+
+
+def tick_transcripts():
+    """What the reference's interaction transcripts show around their tick commands (testdata/*.txt; the harness ticks
+    a node ElectionTick or HeartbeatTick times, rafttest/interaction_env_handler_tick.go:23-39, with the defaults of
+    rafttest/interaction_env.go raftConfigStub).  Per transcript: the two tick constants, the add-nodes line's sets
+    and switches, and every run of tick commands that nothing but comments separates — each command with the lines
+    it printed (a step-down, a campaign) — followed, when the very next command is a `stabilize` or `process-ready`,
+    by the number of MsgHeartbeat lines per destination in the ticked node's first Ready of that command: the
+    heartbeats the ticks produced."""
+    stub = _go("rafttest/interaction_env.go")
+    et = int(re.search(r"ElectionTick:\s*(\d+)", stub).group(1))
+    ht = int(re.search(r"HeartbeatTick:\s*(\d+)", stub).group(1))
+    out = {}
+    for name in TICK_TRANSCRIPTS:
+        lines = open(os.path.join(REF, "testdata", name), encoding="utf-8").read().split("\n")
+        nodes, runs, cur, drawn = None, [], None, []
+        i = 0
+        while i < len(lines):
+            ln = lines[i]
+            m = re.match(r"^set-randomized-election-timeout (\d+) timeout=(\d+)\s*$", ln)
+            if m:
+                drawn.append({"line": i + 1, "node": int(m.group(1)), "timeout": int(m.group(2))})
+            m = ADD_NODES.match(ln)
+            if m and nodes is None:
+                rest = m.group(2)
+
+                def ids(key):
+                    mm = re.search(key + r"=\(([^)]*)\)", rest)
+                    return parse_list(mm.group(1)) if mm and mm.group(1) else []
+                nodes = {"line": i + 1, "count": int(m.group(1)), "voters": ids("voters"), "learners": ids("learners"),
+                         "checkquorum": "checkquorum=true" in rest, "prevote": "prevote=true" in rest}
+            m = TICK_CMD.match(ln)
+            if m and i + 1 < len(lines) and lines[i + 1] == "----":
+                j = i + 2
+                printed = []
+                while j < len(lines) and lines[j] != "":
+                    if lines[j] != "ok":
+                        printed.append(lines[j])
+                    j += 1
+                if cur is None:
+                    cur = {"ticks": [], "next_ready_heartbeats": None}
+                    runs.append(cur)
+                node = int(m.group(2))
+                cur["ticks"].append({"line": i + 1, "kind": m.group(1), "node": node, "n_ticks": et if m.group(1) == "election" else ht,
+                                     "stepped_down": any("stepped down to follower since quorum is not active" in x for x in printed),
+                                     "campaigned": any("is starting a new election" in x for x in printed),
+                                     "printed": len(printed)})
+                i = j
+                continue
+            if cur is not None and ln and not ln.startswith("#"):
+                # the first command after the run
+                mm = re.match(r"^(stabilize|process-ready)( .*)?$", ln)
+                if mm and i + 1 < len(lines) and lines[i + 1] == "----":
+                    node = cur["ticks"][-1]["node"]
+                    j, inside, hb = i + 2, False, {}
+                    while j < len(lines) and lines[j] != "":
+                        if lines[j].startswith("> "):
+                            if inside:
+                                break
+                            inside = lines[j] == "> %d handling Ready" % node
+                        elif inside or mm.group(1) == "process-ready":
+                            h = re.match(r"^\s*%d->(\d+) MsgHeartbeat " % node, lines[j])
+                            if h:
+                                hb[h.group(1)] = hb.get(h.group(1), 0) + 1
+                        j += 1
+                    cur["next_ready_heartbeats"] = hb
+                    cur["next_command_line"] = i + 1
+                cur = None
+            i += 1
+        out[name] = {"election_tick": et, "heartbeat_tick": ht, "nodes": nodes, "set_randomized_election_timeout": drawn, "runs": runs}
+    return out
+
+
 def write_json(path, obj):
     with open(path, "w") as fh:
         json.dump(obj, fh, indent=1)
@@ -634,11 +713,17 @@ def generate(out_dir):
                                      "LastIndex per command, confchange/datadriven_test.go:33-51).  next == last_index in "
                                      "every record (confchange/confchange.go:262).",
                 "init_progress": confchange_init_progress()})
+    write_json(os.path.join(out_dir, "tick_transcripts.json"),
+               {"_doc": "The tick commands of the reference's interaction transcripts with what they printed and the heartbeats "
+                        "the ticked node's next Ready holds (make_golden.py tick_transcripts; no hand edits).  Pins "
+                        "tickHeartbeat / tickElection (raft.go:823-862): how many MsgBeat a run of ticks steps, when "
+                        "CheckQuorum steps a leader down, and that the tick which steps it down sends no heartbeat.",
+                "files": tick_transcripts()})
     return counts
 
 
 GENERATED = ["quorum_datadriven.json", "tables.json", "progress_tables.json", "transcript_facts.json", "figure7.json",
-             "confchange_shapes.json"]
+             "confchange_shapes.json", "tick_transcripts.json"]
 
 
 def main():

@@ -171,5 +171,58 @@ def leader_transfer_timeout(mk):
             assert role == LEADER
 
 
-SCENARIOS = [leader_bcast_beat, nonleader_start_election, learner_election_timeout, leader_stepdown_when_quorum_active,
+def transcript_tick_runs(mk):
+    """tests/golden/tick_transcripts.json — what the reference's interaction transcripts print around their tick
+    commands (generated by make_golden.py from testdata/*.txt).  A run whose ticked node sends heartbeats or steps
+    down is a leader's: the number of ticks that step MsgBeat must equal the MsgHeartbeat count per peer in the node's
+    next Ready, every peer but the node itself (learners too) gets them, and CheckQuorum steps the leader down in
+    exactly the command whose output says so — checkquorum.txt:56-64: six ticks at ElectionTick 3, the step-down in
+    the sixth, five heartbeats per peer, because the tick that steps down sends none (raft.go:852-854).  The peers
+    were active when the run starts (they answered in the stabilize before it; checkquorum.txt:53-55 says so).
+    Otherwise it is a follower's, with the timeout the transcript set (forget_leader.txt:160-179: no campaign in two
+    ticks, a campaign in the third)."""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tick_transcripts.json")) as fh:
+        files = json.load(fh)["files"]
+    leader_runs = follower_runs = 0
+    for name, f in files.items():
+        ids = [int(x) for x in f["nodes"]["voters"]] + [int(x) for x in f["nodes"]["learners"]]
+        S, V = len(ids), len(f["nodes"]["voters"])
+        et, ht = f["election_tick"], f["heartbeat_tick"]
+        drawn = {d["node"]: d["timeout"] for d in f["set_randomized_election_timeout"]}
+        tickers = {}
+        for run in f["runs"]:
+            node = run["ticks"][0]["node"]
+            hb = run["next_ready_heartbeats"]
+            leader = bool(hb) or any(t["stepped_down"] for t in run["ticks"])
+            if not leader and node not in drawn:
+                continue  # a follower whose timeout the transcript does not state
+            if node not in tickers:
+                t = mk(G=1, S=S, election_tick=et, heartbeat_tick=ht, check_quorum=f["nodes"]["checkquorum"], uniform_voters=V)
+                me = 1 << ids.index(node)
+                t.load(role=[LEADER if leader else FOLLOWER], flags=[PROMOTABLE], rt=[drawn.get(node, 2 * et)],
+                       active=[(1 << S) - 1], self_mask=[me])
+                tickers[node] = t
+            t = tickers[node]
+            beats = 0
+            for cmd in run["ticks"]:
+                acts = 0
+                for _ in range(cmd["n_ticks"]):
+                    act, _counts = t.tick()
+                    acts |= int(act[0])
+                    beats += bool(act[0] & BEAT)
+                assert bool(acts & STEP_DOWN) == cmd["stepped_down"], (name, cmd["line"])
+                assert bool(acts & HUP) == cmd["campaigned"], (name, cmd["line"])
+            if leader:
+                leader_runs += 1
+                if hb is not None:
+                    assert sorted(int(k) for k in hb) == sorted(i for i in ids if i != node), (name, run)
+                    assert all(v == beats for v in hb.values()), (name, run, beats)
+            else:
+                follower_runs += 1
+    assert leader_runs >= 7 and follower_runs >= 2, (leader_runs, follower_runs)
+
+
+SCENARIOS = [transcript_tick_runs, leader_bcast_beat, nonleader_start_election, learner_election_timeout, leader_stepdown_when_quorum_active,
              leader_stepdown_when_quorum_lost, leader_transfer_timeout]
