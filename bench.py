@@ -543,6 +543,8 @@ def run_raw_tick(raft_amd, torch, dev, local_rank, stream, reps):
             got = e.read_tick_state(0, n) + (e.read_active(0, n),)
             if not (np.array_equal(e.read_tick_actions(0, n), want_act) and all(np.array_equal(a, b) for a, b in zip(got, want))):
                 raise SystemExit("bench raw tick: GPU result differs from the oracle")
+            # steady state for the timed ticks: every peer has answered since the last CheckQuorum
+            e.upload_active(np.full(G, (1 << S) - 1, dtype=np.uint16))
             t_tick = _timed(stream, lambda: e.tick(counts=False), reps)
             t0 = time.perf_counter()
             counts = e.tick()
