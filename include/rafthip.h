@@ -675,6 +675,14 @@ int rafthip_read_tick_state(rafthip_engine *e, uint64_t first, uint64_t count, u
                             uint32_t *heartbeat_elapsed, uint32_t *randomized_timeout, uint8_t *role,
                             uint8_t *flags);
 int rafthip_tick(rafthip_engine *e, uint64_t *counts);
+/* stepFollower's `r.electionElapsed = 0` (raft.go:1681-1692) for the groups that
+ * heard from their leader since the last tick — MsgApp, MsgHeartbeat or MsgSnap
+ * of the current term: election_elapsed of every listed group becomes 0.  A
+ * list (host or device memory), not a plane: on a host that follows millions of
+ * groups these are the ids its receive path has in hand anyway.  Duplicates are
+ * fine; ids outside the engine are skipped and counted in *rejected (may be
+ * NULL).  Waits for the GPU. */
+int rafthip_tick_heard_from_leader(rafthip_engine *e, const uint32_t *groups, uint64_t n, uint64_t *rejected);
 int rafthip_read_tick_actions(rafthip_engine *e, uint64_t first, uint64_t count, uint8_t *dst);
 /* The groups of the last rafthip_tick whose action byte has a bit of `mask`, in
  * group order, with their action byte: what the host walks instead of the whole

@@ -200,6 +200,17 @@ func (b *BatchEngine) SetTickState(g uint64, electionElapsed, heartbeatElapsed, 
 	})
 }
 
+// HeardFromLeader: stepFollower's r.electionElapsed = 0 (raft.go:1681-1692) for the groups whose leader sent a MsgApp,
+// MsgHeartbeat or MsgSnap of the current term since the last Tick.
+func (b *BatchEngine) HeardFromLeader(groups []uint32) error {
+	if len(groups) == 0 {
+		return nil
+	}
+	return guarded(func() C.int {
+		return C.rafthip_tick_heard_from_leader(b.e, (*C.uint32_t)(unsafe.Pointer(&groups[0])), C.uint64_t(len(groups)), nil)
+	})
+}
+
 // Tick: RawNode.Tick for every group (rawnode.go:64-66 -> tickElection / tickHeartbeat, raft.go:823-862) in one
 // pass.  counts[i] = groups whose action has bit i (Hup, CheckQuorum, StepDown, AbortTransfer, Beat); events receives
 // the groups with an action of mask, in group order, and the call returns how many there are.

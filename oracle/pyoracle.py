@@ -477,6 +477,15 @@ def batch_tick(election_elapsed, heartbeat_elapsed, randomized_timeout, state, f
     return act
 
 
+def tick_heard_from_leader(election_elapsed, groups):
+    """stepFollower's `r.electionElapsed = 0` on MsgApp / MsgHeartbeat / MsgSnap (raft.go:1681-1692) for a list of
+    groups, in place; ids outside the plane are skipped and counted."""
+    g = np.asarray(groups, dtype=np.int64)
+    ok = g < len(election_elapsed)
+    election_elapsed[g[ok]] = 0
+    return int((~ok).sum())
+
+
 def batch_check_quorum(active, nslots, self_mask, in_mask=None, out_mask=None, learner_mask=None,
                        uniform_voters=0):
     """MsgCheckQuorum for every group: returns QuorumActive u8; mutates active (all but self cleared)."""

@@ -53,6 +53,7 @@ SYMBOLS = [
     "rafthip_init_progress_row",
     "rafthip_tick_config", "rafthip_upload_tick_state", "rafthip_read_tick_state", "rafthip_tick",
     "rafthip_read_tick_actions", "rafthip_read_tick_events", "rafthip_emit_heartbeats_due",
+    "rafthip_tick_heard_from_leader",
 ]
 COMM_ID_BYTES = 128
 # RawNode.Tick (rafthip.h RAFTHIP_TICK_*): StateType of raft.go:48-53, action bits, flag bits
@@ -175,6 +176,7 @@ def load_library():
         "rafthip_upload_tick_state": (i32, [vp, u64, u64, vp, vp, vp, vp, vp]),
         "rafthip_read_tick_state": (i32, [vp, u64, u64, vp, vp, vp, vp, vp]),
         "rafthip_tick": (i32, [vp, vp]),
+        "rafthip_tick_heard_from_leader": (i32, [vp, vp, u64, C.POINTER(u64)]),
         "rafthip_read_tick_actions": (i32, [vp, u64, u64, vp]),
         "rafthip_read_tick_events": (i32, [vp, C.c_uint32, vp, u64, C.POINTER(u64)]),
         "rafthip_read_active": (i32, [vp, u64, u64, vp]),
@@ -602,6 +604,19 @@ class Engine:
         out = np.zeros(TICK_ACTIONS, dtype=np.uint64)
         _check(self._L.rafthip_tick(self._h, _ptr(out)))
         return out
+
+    def tick_heard_from_leader(self, groups):
+        """electionElapsed = 0 for the listed groups (numpy uint32 / device tensor / address + count tuple).
+        Returns how many ids lay outside the engine."""
+        if isinstance(groups, tuple):
+            ptr, n = groups
+        else:
+            if isinstance(groups, np.ndarray):
+                groups = np.ascontiguousarray(groups, dtype=np.uint32)
+            ptr, n = groups, len(groups)
+        bad = C.c_uint64()
+        _check(self._L.rafthip_tick_heard_from_leader(self._h, _ptr(ptr) if n else None, n, C.byref(bad)))
+        return bad.value
 
     def read_tick_events(self, mask, max_events=None, dst=None):
         """(events[TICK_EVENT_DTYPE] in group order, total); with dst (device / page-locked address) only the total."""

@@ -2905,6 +2905,31 @@ int rafthip_tick(rafthip_engine* e, uint64_t* counts) {
     return RAFTHIP_OK;
 }
 
+int rafthip_tick_heard_from_leader(rafthip_engine* e, const uint32_t* groups, uint64_t n, uint64_t* rejected) {
+    if (!e) return fail(RAFTHIP_EINVAL, "engine is NULL");
+    if (n && !groups) return fail(RAFTHIP_EINVAL, "groups is NULL");
+    if (n > (1ull << 32)) return fail(RAFTHIP_EINVAL, "at most 2^32 group ids per call");
+    DeviceGuard guard(e->device);
+    int rc;
+    if ((rc = ensure_tick(e))) return rc;
+    if (rejected) *rejected = 0;
+    if (n == 0) return RAFTHIP_OK;
+    const void* d_groups = nullptr;
+    if ((rc = stage_input(e, kStageGroups, groups, (size_t)n * sizeof(u32), &d_groups))) return rc;
+    // the out-of-range count shares the engine's counter words (the tick's own sets are cleared by every counting tick)
+    u64* d_bad = e->d_tick_counts + (kTickCountCopies - 1) * kTickCountStride + kTickActions;
+    HIP_TRY(hipMemsetAsync(d_bad, 0, sizeof(u64), e->stream));
+    hipLaunchKernelGGL(k_tick_heard, dim3((u32)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, e->stream, e->tick_el, e->G,
+                       static_cast<const u32*>(d_groups), (u64)n, d_bad);
+    HIP_TRY(hipGetLastError());
+    u64 bad = 0;
+    if (rejected) HIP_TRY(hipMemcpyAsync(&bad, d_bad, sizeof(u64), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));  // the kernel may have read the caller's own (page-locked) memory
+    e->zero_copy_pending = false;
+    if (rejected) *rejected = bad;
+    return RAFTHIP_OK;
+}
+
 int rafthip_read_tick_events(rafthip_engine* e, uint32_t mask, rafthip_tick_event* dst, uint64_t max_events,
                              uint64_t* n_events) {
     if (!e) return fail(RAFTHIP_EINVAL, "engine is NULL");

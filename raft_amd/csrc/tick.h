@@ -153,6 +153,24 @@ __global__ __launch_bounds__(kBlock) void k_tick(const TickPlanes t, u64 G, int 
     }
 }
 
+// stepFollower's `r.electionElapsed = 0` for the groups that heard from their leader (MsgApp, MsgHeartbeat, MsgSnap:
+// raft.go:1681-1692), as a list of group ids: a store of zero, idempotent, so order and duplicates do not matter.
+__global__ __launch_bounds__(kBlock) void k_tick_heard(u32* __restrict__ election_elapsed, u64 G, const u32* __restrict__ groups,
+                                                       u64 n, u64* __restrict__ rejected) {
+    const u64 i = (u64)blockIdx.x * kBlock + threadIdx.x;
+    bool bad = false;
+    if (i < n) {
+        const u32 g = groups[i];
+        if ((u64)g < G) {
+            election_elapsed[g] = 0;
+        } else {
+            bad = true;
+        }
+    }
+    const u64 b = __ballot(bad);
+    if (b != 0 && (threadIdx.x & 63) == 0) atomicAdd(rejected, (u64)__popcll(b));
+}
+
 // ---------------------------------------------------------------------------
 // The groups of the last pass whose action byte has a bit of `mask`, as (group, action) records in group order
 // (rafthip_read_tick_events): what the host walks instead of the whole action plane — campaigns, step-downs and

@@ -35,6 +35,9 @@ class EngineTicker:
         if self_mask is not None:
             self.e.upload_self(np.ascontiguousarray(self_mask, dtype=self.mdt))
 
+    def heard(self, groups):
+        return self.e.tick_heard_from_leader(np.asarray(groups, dtype=np.uint32))
+
     def tick(self):
         counts = self.e.tick()
         act = self.e.read_tick_actions()
@@ -111,6 +114,15 @@ def test_tick_random_state_every_mask_width(oracle, S, config):
             for name, a, b in zip(("el", "hb", "rt", "role", "flags", "active"), t.state(), o.state()):
                 assert np.array_equal(a, b), (k, name, np.flatnonzero(a != b)[:8])
             total += counts
+            # stepFollower: some groups heard from their leader (duplicates, ids outside the engine, a device-resident list)
+            heard = rng.integers(0, G + 3, size=int(rng.integers(0, 2 * G + 2))).astype(np.uint32)
+            if k % 2:
+                import torch
+                d = torch.from_numpy(heard.view(np.int32)).cuda()
+                bad = t.e.tick_heard_from_leader((d.data_ptr(), len(heard)))
+            else:
+                bad = t.e.tick_heard_from_leader(heard)
+            assert bad == o.heard(heard) == np.count_nonzero(heard >= G)
             check_events(t.e, act, [0xFF, ts.HUP | ts.STEP_DOWN, ts.ABORT_TRANSFER, ts.BEAT, 0][k % 5], cap=[None, 3, 0][k % 3])
             # between ticks: responses arrive (RecentActive, raft.go:1337,1528), a few followers win elections
             a = o.state()[5] | (bits() & bits())

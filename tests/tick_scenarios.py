@@ -40,6 +40,9 @@ class OracleTicker:
                 cur = getattr(self, name)
                 setattr(self, name, np.ascontiguousarray(a, dtype=cur.dtype).copy())
 
+    def heard(self, groups):
+        return self.o.tick_heard_from_leader(self.el, groups)
+
     def tick(self):
         m0, m1, ml = self.masks if self.masks else (None, None, None)
         act = self.o.batch_tick(self.el, self.hb, self.rt, self.role, self.flags, *self.cfg, self.S, self.active,
@@ -224,5 +227,24 @@ def transcript_tick_runs(mk):
     assert leader_runs >= 7 and follower_runs >= 2, (leader_runs, follower_runs)
 
 
-SCENARIOS = [transcript_tick_runs, leader_bcast_beat, nonleader_start_election, learner_election_timeout, leader_stepdown_when_quorum_active,
+def follower_hears_from_leader(mk):
+    """stepFollower resets electionElapsed on every MsgApp / MsgHeartbeat / MsgSnap from the leader
+    (raft.go:1681-1692): a follower that keeps hearing never campaigns, one that stops hearing campaigns one
+    randomized timeout after the last message, one that never hears at the timeout itself
+    (raft_paper_test.go:151-185, the follower case) and again every timeout after that."""
+    et, rt = 10, 13
+    t = mk(G=3, S=3, election_tick=et, heartbeat_tick=1, check_quorum=False, uniform_voters=3)
+    t.load(role=[FOLLOWER] * 3, flags=[PROMOTABLE] * 3, rt=[rt] * 3)
+    fired = [[], [], []]
+    for i in range(1, 3 * rt + 1):
+        assert t.heard([0] if i > 5 else [0, 1, 1]) == 0
+        act, _ = t.tick()
+        for g in range(3):
+            if act[g] & HUP:
+                fired[g].append(i)
+    assert fired == [[], [5 + rt - 1, 5 + 2 * rt - 1], [rt, 2 * rt, 3 * rt]], fired
+    assert t.heard([2, 7, 1 << 20]) == 2  # ids outside the engine are skipped and counted
+
+
+SCENARIOS = [transcript_tick_runs, follower_hears_from_leader, leader_bcast_beat, nonleader_start_election, learner_election_timeout, leader_stepdown_when_quorum_active,
              leader_stepdown_when_quorum_lost, leader_transfer_timeout]

@@ -266,6 +266,17 @@ int main(void) {
         OK(rafthip_upload_tick_state(e, FIRST, COUNT, el, hb, rt, role, fl));
         OK(rafthip_upload_tick_state(e, FIRST, COUNT, NULL, NULL, NULL, role, NULL));
         OK(rafthip_tick(e, counts));
+        {
+            uint32_t *heard = buf(777 * 4);
+            uint64_t bad = 0, want_bad = 0;
+            for (int i = 0; i < 777; i++) heard[i] %= G + 50, want_bad += heard[i] >= G;
+            OK(rafthip_tick_heard_from_leader(e, heard, 777, &bad));
+            OK(rafthip_tick_heard_from_leader(e, heard, 777, NULL));
+            OK(rafthip_tick_heard_from_leader(e, NULL, 0, &bad) || bad != 0);
+            FAILS(rafthip_tick_heard_from_leader(e, NULL, 5, &bad));
+            OK(rafthip_tick_heard_from_leader(e, heard, 777, &bad));
+            if (bad != want_bad) { fprintf(stderr, "heard: %llu rejected, want %llu\n", (unsigned long long)bad, (unsigned long long)want_bad); return 1; }
+        }
         OK(rafthip_tick(e, NULL));
         OK(rafthip_tick(e, counts));
         OK(rafthip_read_tick_actions(e, 0, G, buf(G)));
