@@ -228,6 +228,10 @@ int main() {
                 rc = trk->SetTickConfig((uint32_t)u(1), (uint32_t)u(2), u(3) != 0);
             } else if (cmd == "tickstate") {  // group el hb rt state promotable transferring
                 rc = trk->SetTickState(u(1), (uint32_t)u(2), (uint32_t)u(3), (uint32_t)u(4), (int)u(5), u(6) != 0, u(7) != 0);
+            } else if (cmd == "heard") {  // groups=g,g,...
+                std::vector<uint32_t> gs;
+                for (const auto& x : split(arg(t, "groups"), ',')) gs.push_back((uint32_t)strtoul(x.c_str(), nullptr, 10));
+                rc = trk->HeardFromLeader(gs);
             } else if (cmd == "tick") {  // event mask
                 std::vector<tracker::BatchProgressTracker::TickEvent> ev;
                 uint64_t c[5];

@@ -514,6 +514,14 @@ int BatchProgressTracker::SetTickState(uint64_t group, uint32_t election_elapsed
     return lib(rafthip_upload_tick_state(e_, group, 1, &election_elapsed, &heartbeat_elapsed, &randomized_timeout, &role, &flags));
 }
 
+int BatchProgressTracker::HeardFromLeader(const std::vector<uint32_t>& groups) {
+    uint64_t outside = 0;
+    int rc = lib(rafthip_tick_heard_from_leader(e_, groups.data(), groups.size(), &outside));
+    if (rc) return rc;
+    if (outside) return fail(RAFTHIP_ERANGE, "%llu group ids outside [0, %llu)", (unsigned long long)outside, (unsigned long long)G_);
+    return RAFTHIP_OK;
+}
+
 int BatchProgressTracker::Tick(uint32_t event_mask, std::vector<TickEvent>* events, uint64_t counts[5]) {
     int rc = Flush();  // queued responses set RecentActive before the tick looks at it
     if (rc) return rc;

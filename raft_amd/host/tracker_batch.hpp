@@ -133,6 +133,9 @@ class BatchProgressTracker {
     int SetTickState(uint64_t group, uint32_t election_elapsed, uint32_t heartbeat_elapsed, uint32_t randomized_timeout,
                      int state, bool promotable, bool transferring);
     int Tick(uint32_t event_mask, std::vector<TickEvent>* events, uint64_t counts[5]);
+    // stepFollower's r.electionElapsed = 0 for the groups whose leader sent a MsgApp, MsgHeartbeat or MsgSnap of the
+    // current term since the last Tick (raft.go:1681-1692).
+    int HeardFromLeader(const std::vector<uint32_t>& groups);
     // sendHeartbeat's commit for peer `id` (raft.go:669-685), after MaybeCommit().
     int HeartbeatCommit(uint64_t group, uint64_t id, uint64_t* commit);
 

@@ -426,6 +426,10 @@ def test_tracker_raw_node_tick(oracle):
                 want.append("dropped")
             else:
                 m.active[g][i] = True
+        heard = sorted(set(rng.integers(0, G, size=G // 3).tolist()))  # stepFollower: electionElapsed = 0 (raft.go:1681-1692)
+        script.append("heard groups=%s" % ",".join(str(g) for g in heard))
+        for g in heard:
+            st[g][0] = 0
         script.append("tick %d" % mask)
         counts = [0] * 5
         for g in range(G):
