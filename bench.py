@@ -538,8 +538,10 @@ def run_raw_tick(raft_amd, torch, dev, local_rank, stream, reps):
         with torch.cuda.stream(stream):
             e.tick(counts=False)
             want = [a[:n].copy() for a in (el, hb, rt, role, flags, active)]
+            c0 = time.perf_counter()
             want_act = po.batch_tick(want[0], want[1], want[2], want[3], want[4], et, ht, True, S, want[5],
                                      self_mask[:n].copy(), uniform_voters=V)
+            t_cpu = time.perf_counter() - c0
             got = e.read_tick_state(0, n) + (e.read_active(0, n),)
             if not (np.array_equal(e.read_tick_actions(0, n), want_act) and all(np.array_equal(a, b) for a, b in zip(got, want))):
                 raise SystemExit("bench raw tick: GPU result differs from the oracle")
@@ -556,7 +558,8 @@ def run_raw_tick(raft_amd, torch, dev, local_rank, stream, reps):
                 "frac_of_hbm_peak": round(G * 23 / t_tick / 1e9 / HBM_PEAK_GBS, 4), "kernel": "k_tick<uint16_t>",
                 "counts_hup_checkquorum_stepdown_aborttransfer_beat": [int(c) for c in counts],
                 "tick_with_counts_and_event_list_wall_ms": round(t_ev * 1e3, 3), "events_listed": int(n_ev),
-                "oracle_checked_groups": n}
+                "oracle_checked_groups": n,
+                "cpu_port_1_thread_groups_per_s": n / t_cpu}  # oracle_batch_tick on the checked slice: the reference's loop shape
 
 
 def main():
