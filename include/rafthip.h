@@ -675,6 +675,13 @@ int rafthip_read_tick_state(rafthip_engine *e, uint64_t first, uint64_t count, u
                             uint32_t *heartbeat_elapsed, uint32_t *randomized_timeout, uint8_t *role,
                             uint8_t *flags);
 int rafthip_tick(rafthip_engine *e, uint64_t *counts);
+/* The same tick for the shards (engines) of one GPU in ONE launch, for a host that
+ * keeps several shards per GPU (as rafthip_commit_many): every shard with its own
+ * planes, config and tick constants; counts (may be NULL) receives
+ * RAFTHIP_TICK_ACTIONS words per engine.  Engines of one GPU and one mask width
+ * share the launch (16 at a time); otherwise the call ticks them one by one.
+ * Engines on different streams are joined as in rafthip_commit_many. */
+int rafthip_tick_many(rafthip_engine *const *engines, uint32_t n, uint64_t *counts);
 /* stepFollower's `r.electionElapsed = 0` (raft.go:1681-1692) for the groups that
  * heard from their leader since the last tick — MsgApp, MsgHeartbeat or MsgSnap
  * of the current term: election_elapsed of every listed group becomes 0.  A

@@ -200,6 +200,20 @@ func (b *BatchEngine) SetTickState(g uint64, electionElapsed, heartbeatElapsed, 
 	})
 }
 
+// TickMany: Tick for the shards (engines) of one GPU in one launch (rafthip_tick_many); counts[i] belongs to
+// engines[i].  The handles are C pointers (as in CommitMany), so the array may be Go memory.
+func TickMany(engines []*BatchEngine, counts [][5]uint64) error {
+	hs := make([]*C.rafthip_engine, len(engines))
+	for i, b := range engines {
+		hs[i] = b.e
+	}
+	var p *C.uint64_t
+	if len(counts) > 0 {
+		p = (*C.uint64_t)(unsafe.Pointer(&counts[0][0]))
+	}
+	return guarded(func() C.int { return C.rafthip_tick_many(&hs[0], C.uint32_t(len(hs)), p) })
+}
+
 // HeardFromLeader: stepFollower's r.electionElapsed = 0 (raft.go:1681-1692) for the groups whose leader sent a MsgApp,
 // MsgHeartbeat or MsgSnap of the current term since the last Tick.
 func (b *BatchEngine) HeardFromLeader(groups []uint32) error {

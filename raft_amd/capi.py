@@ -53,7 +53,7 @@ SYMBOLS = [
     "rafthip_init_progress_row",
     "rafthip_tick_config", "rafthip_upload_tick_state", "rafthip_read_tick_state", "rafthip_tick",
     "rafthip_read_tick_actions", "rafthip_read_tick_events", "rafthip_emit_heartbeats_due",
-    "rafthip_tick_heard_from_leader",
+    "rafthip_tick_heard_from_leader", "rafthip_tick_many",
 ]
 COMM_ID_BYTES = 128
 # RawNode.Tick (rafthip.h RAFTHIP_TICK_*): StateType of raft.go:48-53, action bits, flag bits
@@ -176,6 +176,7 @@ def load_library():
         "rafthip_upload_tick_state": (i32, [vp, u64, u64, vp, vp, vp, vp, vp]),
         "rafthip_read_tick_state": (i32, [vp, u64, u64, vp, vp, vp, vp, vp]),
         "rafthip_tick": (i32, [vp, vp]),
+        "rafthip_tick_many": (i32, [vp, C.c_uint32, vp]),
         "rafthip_tick_heard_from_leader": (i32, [vp, vp, u64, C.POINTER(u64)]),
         "rafthip_read_tick_actions": (i32, [vp, u64, u64, vp]),
         "rafthip_read_tick_events": (i32, [vp, C.c_uint32, vp, u64, C.POINTER(u64)]),
@@ -709,6 +710,17 @@ class EngineSet:
     def commit(self, n=None):
         """One launch over the first n engines (default: all)."""
         _check(self._L.rafthip_commit_many(self._arr, len(self.engines) if n is None else n))
+
+    def tick(self, counts=True, n=None):
+        """rafthip_tick_many: RawNode.Tick for every group of the first n engines (default: all) in one launch.
+        Returns the per-action counts, one row of TICK_ACTIONS per engine, or None."""
+        n = len(self.engines) if n is None else n
+        if not counts:
+            _check(self._L.rafthip_tick_many(self._arr, n, None))
+            return None
+        out = np.zeros((n, TICK_ACTIONS), dtype=np.uint64)
+        _check(self._L.rafthip_tick_many(self._arr, n, _ptr(out)))
+        return out
 
     def commit_report(self, advance=False, max_pairs=None, dsts=None):
         """rafthip_commit_report_many: commit_changed / commit_advance of every engine in one call.  Returns

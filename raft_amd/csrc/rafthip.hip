@@ -2853,19 +2853,141 @@ int rafthip_read_tick_actions(rafthip_engine* e, uint64_t first, uint64_t count,
     return RAFTHIP_OK;
 }
 
-int rafthip_tick(rafthip_engine* e, uint64_t* counts) {
-    if (!e) return fail(RAFTHIP_EINVAL, "engine is NULL");
+// What a tick of engine e needs before its kernel can run (the caller has made e's device current).
+static int tick_prepare(rafthip_engine* e) {
     if (e->election_timeout == 0) return fail(RAFTHIP_EINVAL, "rafthip_tick_config has not been called");
-    DeviceGuard guard(e->device);
     int rc;
     if ((rc = ensure_tick(e))) return rc;
-    const bool uni = e->uniform && e->uniform_voters > 0;
     if (e->check_quorum) {
         if (!e->active) return fail(RAFTHIP_EINVAL, "RecentActive bits have not been uploaded");
         // groups whose self mask was never uploaded keep no bit, as in rafthip_check_quorum
         if ((rc = ensure(e, e->self_mask, (size_t)e->stride * e->mbytes))) return rc;
         if (e->uniform && e->uniform_voters == 0 && (rc = ensure_masks(e))) return rc;
     }
+    return RAFTHIP_OK;
+}
+
+// The per-action counts of engine e's last counting tick, summed over the counter sets (after the stream has drained).
+static void tick_sum_counts(const u64* sets, uint64_t* counts) {
+    for (int b = 0; b < kTickActions; ++b) {
+        u64 sum = 0;
+        for (int c = 0; c < kTickCountCopies; ++c) sum += sets[c * kTickCountStride + b];
+        counts[b] = sum;
+    }
+}
+
+int rafthip_tick_many(rafthip_engine* const* engines, uint32_t n, uint64_t* counts) {
+    if (!engines || n == 0) return fail(RAFTHIP_EINVAL, "engines is NULL or n is 0");
+    for (u32 i = 0; i < n; ++i)
+        if (!engines[i]) return fail(RAFTHIP_EINVAL, "engines[%u] is NULL", i);
+    rafthip_engine* e0 = engines[0];
+    // one launch needs one GPU and one mask width; anything else is the per-engine pass, engine by engine
+    bool same = true;
+    for (u32 i = 1; i < n; ++i)
+        if (engines[i]->device != e0->device || engines[i]->mbytes != e0->mbytes) same = false;
+    if (!same || n == 1) {
+        for (u32 i = 0; i < n; ++i) {
+            int rc = rafthip_tick(engines[i], counts ? counts + (size_t)i * RAFTHIP_TICK_ACTIONS : nullptr);
+            if (rc) return rc;
+        }
+        return RAFTHIP_OK;
+    }
+    DeviceGuard guard(e0->device);
+    int rc;
+    for (u32 i = 0; i < n; ++i)
+        if ((rc = tick_prepare(engines[i]))) return rc;
+    hipStream_t st = e0->stream;
+    hipEvent_t ev = nullptr;
+    bool one_stream = true;
+    for (u32 i = 1; i < n; ++i)
+        if (engines[i]->stream != st) one_stream = false;
+    if (!one_stream) {  // as rafthip_commit_many: the launch waits for what the other engines' streams hold, and they for it
+        HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        for (u32 i = 1; i < n; ++i) {
+            if (engines[i]->stream == st) continue;
+            hipError_t err = hipStreamQuery(engines[i]->stream);
+            if (err == hipSuccess) continue;
+            if (err != hipErrorNotReady) {
+                (void)hipEventDestroy(ev);
+                return fail(RAFTHIP_EIO, "hipStreamQuery: %s", hipGetErrorString(err));
+            }
+            (void)hipGetLastError();
+            err = hipEventRecord(ev, engines[i]->stream);
+            if (err == hipSuccess) err = hipStreamWaitEvent(st, ev, 0);
+            if (err != hipSuccess) {
+                (void)hipEventDestroy(ev);
+                return fail(RAFTHIP_EIO, "stream join: %s", hipGetErrorString(err));
+            }
+        }
+    }
+    rc = RAFTHIP_OK;
+    for (u32 lo = 0; lo < n && !rc; lo += kTickManyMax) {
+        TickShards sh{};
+        sh.n = n - lo < (u32)kTickManyMax ? n - lo : (u32)kTickManyMax;
+        u32 blocks = 0;
+        for (u32 k = 0; k < sh.n && !rc; ++k) {
+            rafthip_engine* e = engines[lo + k];
+            const bool uni = e->uniform && e->uniform_voters > 0;
+            sh.first_block[k] = blocks;
+            sh.planes[k] = TickPlanes{e->tick_el, e->tick_hb, e->tick_rt, e->tick_role, e->tick_flags, e->tick_action};
+            sh.groups[k] = e->G;
+            sh.active[k] = e->active;
+            sh.in_mask[k] = uni ? nullptr : e->in_mask;
+            sh.out_mask[k] = uni ? nullptr : e->out_mask;
+            sh.learner_mask[k] = uni ? nullptr : e->learner_mask;
+            sh.self_mask[k] = e->self_mask;
+            sh.counts[k] = counts ? e->d_tick_counts : nullptr;
+            sh.election_timeout[k] = e->election_timeout;
+            sh.heartbeat_timeout[k] = e->heartbeat_timeout;
+            sh.check_quorum[k] = e->check_quorum ? 1 : 0;
+            sh.slots[k] = (uint8_t)e->S;
+            sh.uniform_voters[k] = (uint8_t)e->uniform_voters;
+            blocks += (u32)((e->G + (u64)kBlock * 4 - 1) / ((u64)kBlock * 4));
+            e->stats.groups_evaluated += e->G;
+            if (counts) {
+                hipError_t err = hipMemsetAsync(e->d_tick_counts, 0, sizeof(u64) * kTickCountCopies * kTickCountStride, st);
+                if (err != hipSuccess) rc = fail(RAFTHIP_EIO, "hipMemsetAsync: %s", hipGetErrorString(err));
+            }
+        }
+        sh.first_block[sh.n] = blocks;
+        if (rc) break;
+        if (e0->mbytes == 1) {
+            hipLaunchKernelGGL((k_tick_many<uint8_t>), dim3(blocks), dim3(kBlock), 0, st, sh);
+        } else if (e0->mbytes == 2) {
+            hipLaunchKernelGGL((k_tick_many<uint16_t>), dim3(blocks), dim3(kBlock), 0, st, sh);
+        } else if (e0->mbytes == 4) {
+            hipLaunchKernelGGL((k_tick_many<uint32_t>), dim3(blocks), dim3(kBlock), 0, st, sh);
+        } else {
+            hipLaunchKernelGGL((k_tick_many<uint64_t>), dim3(blocks), dim3(kBlock), 0, st, sh);
+        }
+        hipError_t err = hipGetLastError();
+        if (err != hipSuccess) rc = fail(RAFTHIP_EIO, "k_tick_many: %s", hipGetErrorString(err));
+    }
+    if (ev) {
+        hipError_t err = hipEventRecord(ev, st);
+        for (u32 i = 1; i < n && err == hipSuccess; ++i)
+            if (engines[i]->stream != st) err = hipStreamWaitEvent(engines[i]->stream, ev, 0);
+        (void)hipEventDestroy(ev);
+        if (err != hipSuccess && !rc) rc = fail(RAFTHIP_EIO, "stream join: %s", hipGetErrorString(err));
+    }
+    if (rc || !counts) return rc;
+    // the counter sets of every shard in one wait
+    std::vector<u64> sets((size_t)n * kTickCountCopies * kTickCountStride);
+    for (u32 i = 0; i < n; ++i)
+        HIP_TRY(hipMemcpyAsync(sets.data() + (size_t)i * kTickCountCopies * kTickCountStride, engines[i]->d_tick_counts,
+                               sizeof(u64) * kTickCountCopies * kTickCountStride, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (u32 i = 0; i < n; ++i)
+        tick_sum_counts(sets.data() + (size_t)i * kTickCountCopies * kTickCountStride, counts + (size_t)i * RAFTHIP_TICK_ACTIONS);
+    return RAFTHIP_OK;
+}
+
+int rafthip_tick(rafthip_engine* e, uint64_t* counts) {
+    if (!e) return fail(RAFTHIP_EINVAL, "engine is NULL");
+    DeviceGuard guard(e->device);
+    int rc;
+    if ((rc = tick_prepare(e))) return rc;
+    const bool uni = e->uniform && e->uniform_voters > 0;
     hipStream_t st = e->stream;
     static_assert(kTickActions == RAFTHIP_TICK_ACTIONS && kTickActions <= kTickCountStride, "rafthip.h and tick.h disagree");
     if (counts) HIP_TRY(hipMemsetAsync(e->d_tick_counts, 0, sizeof(u64) * kTickCountCopies * kTickCountStride, st));
@@ -2896,11 +3018,7 @@ int rafthip_tick(rafthip_engine* e, uint64_t* counts) {
         u64 sets[kTickCountCopies * kTickCountStride];
         HIP_TRY(hipMemcpyAsync(sets, e->d_tick_counts, sizeof(sets), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
-        for (int b = 0; b < kTickActions; ++b) {
-            u64 sum = 0;
-            for (int c = 0; c < kTickCountCopies; ++c) sum += sets[c * kTickCountStride + b];
-            counts[b] = sum;
-        }
+        tick_sum_counts(sets, counts);
     }
     return RAFTHIP_OK;
 }

@@ -36,16 +36,17 @@ struct TickPlanes {
 // all workgroups made the pass three times as long: 65 536 workgroups x 4 atomics on the same five words); the host
 // adds the sets up.
 constexpr int kTickCountCopies = 256, kTickCountStride = 8;  // words per set: 64 bytes
+// One workgroup's 1024 groups of one engine; `block` is the workgroup's index within that engine.
 template <typename MaskT>
-__global__ __launch_bounds__(kBlock) void k_tick(const TickPlanes t, u64 G, int S, u32 election_timeout,
-                                                 u32 heartbeat_timeout, u32 check_quorum, MaskT* __restrict__ active,
-                                                 const MaskT* __restrict__ in_mask, const MaskT* __restrict__ out_mask,
-                                                 const MaskT* __restrict__ learner_mask, int uniform_voters,
-                                                 const MaskT* __restrict__ self_mask, u64* __restrict__ counts) {
+__device__ __forceinline__ void tick_block(const TickPlanes t, u64 G, int S, u32 election_timeout, u32 heartbeat_timeout,
+                                           u32 check_quorum, MaskT* __restrict__ active, const MaskT* __restrict__ in_mask,
+                                           const MaskT* __restrict__ out_mask, const MaskT* __restrict__ learner_mask,
+                                           int uniform_voters, const MaskT* __restrict__ self_mask, u64* __restrict__ counts,
+                                           u32 block) {
     __shared__ u32 wg_counts[kTickActions];
     if (threadIdx.x < kTickActions) wg_counts[threadIdx.x] = 0;
     __syncthreads();
-    const u64 g0 = ((u64)blockIdx.x * kBlock + threadIdx.x) * 4;  // < stride (a multiple of 4096)
+    const u64 g0 = ((u64)block * kBlock + threadIdx.x) * 4;  // < stride (a multiple of 4096)
     const u64 slots = S >= 64 ? kU64Max : ((1ull << S) - 1ull);
     Vec<u32, 4> EL = load_stream<u32, 4>(t.election_elapsed + g0);
     Vec<u32, 4> HB = load_stream<u32, 4>(t.heartbeat_elapsed + g0);
@@ -149,8 +150,49 @@ __global__ __launch_bounds__(kBlock) void k_tick(const TickPlanes t, u64 G, int 
         }
         __syncthreads();
         if (threadIdx.x < kTickActions && wg_counts[threadIdx.x])
-            atomicAdd(counts + (blockIdx.x % kTickCountCopies) * kTickCountStride + threadIdx.x, (u64)wg_counts[threadIdx.x]);
+            atomicAdd(counts + (block % kTickCountCopies) * kTickCountStride + threadIdx.x, (u64)wg_counts[threadIdx.x]);
     }
+}
+
+template <typename MaskT>
+__global__ __launch_bounds__(kBlock) void k_tick(const TickPlanes t, u64 G, int S, u32 election_timeout,
+                                                 u32 heartbeat_timeout, u32 check_quorum, MaskT* __restrict__ active,
+                                                 const MaskT* __restrict__ in_mask, const MaskT* __restrict__ out_mask,
+                                                 const MaskT* __restrict__ learner_mask, int uniform_voters,
+                                                 const MaskT* __restrict__ self_mask, u64* __restrict__ counts) {
+    tick_block<MaskT>(t, G, S, election_timeout, heartbeat_timeout, check_quorum, active, in_mask, out_mask, learner_mask,
+                      uniform_voters, self_mask, counts, blockIdx.x);
+}
+
+// K12m — the same pass over the shards of several engines of one GPU in ONE launch (rafthip_tick_many), for the
+// host that keeps several shards per GPU (K1m's reason: a 2^20-group shard's tick moves 24 MB and ends after a few
+// microseconds, as long as the boundary between two kernels).  The shard table travels by value in the kernel
+// arguments; every shard keeps its own planes, config, tick constants and counter sets.
+constexpr int kTickManyMax = 16;
+struct TickShards {
+    u32 n;
+    u32 first_block[kTickManyMax + 1];
+    TickPlanes planes[kTickManyMax];
+    u64 groups[kTickManyMax];
+    void* active[kTickManyMax];
+    const void* in_mask[kTickManyMax];
+    const void* out_mask[kTickManyMax];
+    const void* learner_mask[kTickManyMax];
+    const void* self_mask[kTickManyMax];
+    u64* counts[kTickManyMax];
+    u32 election_timeout[kTickManyMax], heartbeat_timeout[kTickManyMax];
+    uint8_t check_quorum[kTickManyMax], slots[kTickManyMax], uniform_voters[kTickManyMax];
+};
+
+template <typename MaskT>
+__global__ __launch_bounds__(kBlock) void k_tick_many(const TickShards sh) {
+    u32 k = 0;
+    for (u32 i = 1; i < sh.n; ++i) k = blockIdx.x >= sh.first_block[i] ? i : k;  // wave-uniform: scalar loads + compares
+    tick_block<MaskT>(sh.planes[k], sh.groups[k], (int)sh.slots[k], sh.election_timeout[k], sh.heartbeat_timeout[k],
+                      sh.check_quorum[k], static_cast<MaskT*>(sh.active[k]), static_cast<const MaskT*>(sh.in_mask[k]),
+                      static_cast<const MaskT*>(sh.out_mask[k]), static_cast<const MaskT*>(sh.learner_mask[k]),
+                      (int)sh.uniform_voters[k], static_cast<const MaskT*>(sh.self_mask[k]), sh.counts[k],
+                      blockIdx.x - sh.first_block[k]);
 }
 
 // stepFollower's `r.electionElapsed = 0` for the groups that heard from their leader (MsgApp, MsgHeartbeat, MsgSnap:

@@ -200,3 +200,74 @@ def test_tick_a_million_groups(oracle):
             assert np.array_equal(pin["group"], want[:1000])
     finally:
         t.close()
+
+
+@pytest.mark.parametrize("S", [5, 9])
+def test_tick_many_shards_in_one_launch(oracle, S):
+    """rafthip_tick_many: the shards of several engines in one launch — ragged sizes, uniform and masked configs, each
+    shard with its own tick constants — every shard against its own oracle after each of eight ticks; then engines of
+    another mask width in the list (the call ticks them one by one) and engines on streams of their own."""
+    import torch
+    rng = np.random.default_rng(7600 + S)
+    mdt = gu.mask_dtype(S)
+    sizes = [1, 1023, 1024, 1025, 4097, 9000, 5, 2048, 3333, 4096, 100, 7777, 1, 2, 3, 4, 5000, 600, 70]  # > 16: two launches
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    shards = []
+    try:
+        for i, G in enumerate(sizes):
+            masks = None
+            V = 1 + i % S
+            if i % 3 == 0:
+                m0, m1 = rand_masks(rng, S, G, joint_frac=0.5, empty_frac=0.05)
+                masks = (m0, m1, ((~(m0 | m1)) & mdt((1 << S) - 1)).astype(mdt))
+            et, ht, cq = 3 + i % 4, 1 + i % 2, i % 5 != 0
+            o = ts.OracleTicker(oracle, G, S, et, ht, cq, uniform_voters=0 if masks else V, masks=masks)
+            t = EngineTicker(G, S, et, ht, cq, uniform_voters=0 if masks else V, masks=masks)
+            if i % 4 == 1:  # an engine on a stream of its own
+                t.close()
+                t.e = raft_amd.Engine(G, S, stream=streams[i % 3].cuda_stream)
+                if masks:
+                    t.e.upload_config(*masks)
+                else:
+                    t.e.set_uniform_config(V)
+                t.e.tick_config(et, ht, cq)
+                t.e.upload_active(np.zeros(G, mdt))
+                t.e.upload_self(np.zeros(G, mdt))
+            init = dict(el=rng.integers(0, 2 * et, G), hb=rng.integers(0, ht + 1, G), rt=rng.integers(et, 2 * et, G),
+                        role=rng.integers(0, 4, G), flags=rng.integers(0, 4, G),
+                        active=rng.integers(0, 1 << S, G).astype(mdt) & rng.integers(0, 1 << S, G).astype(mdt),
+                        self_mask=(1 << rng.integers(0, S, G)).astype(mdt))
+            o.load(**init)
+            t.load(**init)
+            shards.append((o, t))
+        es = raft_amd.capi.EngineSet([t.e for _, t in shards])
+        for k in range(8):
+            counts = es.tick(counts=(k != 3))
+            for i, (o, t) in enumerate(shards):
+                want_act, want_counts = o.tick()
+                assert np.array_equal(t.e.read_tick_actions(), want_act), (k, i)
+                if counts is not None:
+                    assert np.array_equal(counts[i], want_counts), (k, i)
+                for name, a, b in zip(("el", "hb", "rt", "role", "flags", "active"), t.state(), o.state()):
+                    assert np.array_equal(a, b), (k, i, name)
+                a = o.state()[5] | (rng.integers(0, 1 << S, o.G).astype(mdt) & rng.integers(0, 1 << S, o.G).astype(mdt))
+                o.load(active=a)
+                t.load(active=a)
+        # another mask width in the list: ticked one by one, same results
+        G2, S2 = 3000, 20
+        o2 = ts.OracleTicker(oracle, G2, S2, 4, 1, True, uniform_voters=11)
+        t2 = EngineTicker(G2, S2, 4, 1, True, uniform_voters=11)
+        shards.append((o2, t2))
+        init = dict(el=rng.integers(0, 8, G2), hb=np.zeros(G2), rt=rng.integers(4, 8, G2), role=rng.integers(0, 4, G2),
+                    flags=rng.integers(0, 4, G2), active=rng.integers(0, 1 << S2, G2).astype(np.uint32),
+                    self_mask=np.ones(G2, np.uint32))
+        o2.load(**init)
+        t2.load(**init)
+        es = raft_amd.capi.EngineSet([t.e for _, t in shards[:3]] + [t2.e])
+        counts = es.tick()
+        for i, (o, t) in enumerate(shards[:3] + [(o2, t2)]):
+            want_act, want_counts = o.tick()
+            assert np.array_equal(t.e.read_tick_actions(), want_act) and np.array_equal(counts[i], want_counts), i
+    finally:
+        for _, t in shards:
+            t.close()

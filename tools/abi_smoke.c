@@ -278,6 +278,14 @@ int main(void) {
             if (bad != want_bad) { fprintf(stderr, "heard: %llu rejected, want %llu\n", (unsigned long long)bad, (unsigned long long)want_bad); return 1; }
         }
         OK(rafthip_tick(e, NULL));
+        {
+            rafthip_engine *two[2] = {e, e};
+            uint64_t c2[2 * RAFTHIP_TICK_ACTIONS];
+            OK(rafthip_tick_many(two, 1, c2));
+            OK(rafthip_tick_many(two, 1, NULL));
+            FAILS(rafthip_tick_many(two, 0, NULL));
+            FAILS(rafthip_tick_many(NULL, 1, NULL));
+        }
         OK(rafthip_tick(e, counts));
         OK(rafthip_read_tick_actions(e, 0, G, buf(G)));
         OK(rafthip_read_tick_actions(e, FIRST, COUNT, act));

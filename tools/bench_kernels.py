@@ -219,6 +219,29 @@ def main():
         timed("k_tick RawNode.Tick, 40 % leaders, CheckQuorum (K12)", "group", G, 23, lambda: e.tick(counts=False))
         e.upload_active(bits)
         timed("k_tick + the counts read back (K12)", "group", G, 23, e.tick, iters=5)
+        # K12m: twelve shards of 2^20 groups, one launch against one launch each
+        if not args.only or args.only in "k_tick_many (K12m)":
+            Gs = (1 << 20) >> sh
+            shards = []
+            for k in range(12):
+                es_ = raft_amd.Engine(Gs, 5, stream=stream.cuda_stream)
+                es_.set_uniform_config(5)
+                es_.tick_config(10, 1, True)
+                es_.upload_tick_state(rng.integers(0, 10, size=Gs, dtype=np.uint32), np.zeros(Gs, dtype=np.uint32),
+                                      rng.integers(10, 20, size=Gs, dtype=np.uint32),
+                                      np.where(rng.random(Gs) < 0.4, 2, 0).astype(np.uint8), np.ones(Gs, dtype=np.uint8))
+                es_.upload_active(np.full(Gs, 31, dtype=np.uint8))
+                es_.upload_self(np.ones(Gs, dtype=np.uint8))
+                shards.append(es_)
+            eset = S.EngineSet(shards)
+            timed("k_tick_many, 12 shards of 2^20 groups, one launch (K12m)", "group", 12 * Gs, 23, lambda: eset.tick(counts=False))
+
+            def one_by_one():
+                for x in shards:
+                    x.tick(counts=False)
+            timed("k_tick, the same 12 shards, one launch each (K12)", "group", 12 * Gs, 23, one_by_one)
+            for x in shards:
+                x.close()
         m0 = np.full(G, 0b11111, dtype=np.uint8)
         e.upload_config(m0, m0 >> 1, np.zeros(G, dtype=np.uint8))
         timed("k_tally_votes_small<5> masked joint (K3)", "group", G, 5 + 3 + 3, e.tally_votes)
