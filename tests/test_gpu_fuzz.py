@@ -81,6 +81,20 @@ def test_random_call_sequences(oracle, S, G, seed):
                   role=np.zeros(G, np.uint8), flags=np.zeros(G, np.uint8))
         e.tick_config(4, 2, True)
         ticks = 0
+        # a second, small engine of the same mask width, so that every other tick goes through rafthip_tick_many
+        import tick_scenarios as ts
+        G2 = 37
+        e2 = raft_amd.Engine(G2, S)
+        e2.set_uniform_config(S)
+        e2.tick_config(3, 1, True)
+        o2 = ts.OracleTicker(oracle, G2, S, 3, 1, True, uniform_voters=S)
+        init2 = dict(role=rng2.integers(0, 4, G2), flags=rng2.integers(0, 4, G2), rt=rng2.integers(3, 6, G2),
+                     active=np.full(G2, 1, mdt), self_mask=np.full(G2, 1, mdt))
+        o2.load(**init2)
+        e2.upload_tick_state(None, None, o2.rt, o2.role, o2.flags)
+        e2.upload_active(o2.active)
+        e2.upload_self(o2.self_mask)
+        both = raft_amd.capi.EngineSet([e, e2])
         for step in range(170):
             if step % 5 == 4:
                 if rng2.random() < 0.4:  # reset / becomeLeader / a transfer on a range of groups
@@ -93,9 +107,17 @@ def test_random_call_sequences(oracle, S, G, seed):
                     e.upload_tick_state(tk["el"][b:b + k], tk["hb"][b:b + k], tk["rt"][b:b + k], tk["role"][b:b + k],
                                         tk["flags"][b:b + k], first=b, count=k)
                 else:
+                    heard = rng2.integers(0, G + 2, size=int(rng2.integers(0, G + 1))).astype(np.uint32)  # stepFollower
+                    assert e.tick_heard_from_leader(heard) == po.tick_heard_from_leader(tk["el"], heard), step
                     want = po.batch_tick(tk["el"], tk["hb"], tk["rt"], tk["role"], tk["flags"], 4, 2, True, S, sh["active"],
                                          sh["self"], **lrn_kw())
-                    counts = e.tick()
+                    if ticks % 2:
+                        counts = e.tick()
+                    else:
+                        c2 = both.tick()
+                        counts = c2[0]
+                        want2, want2_counts = o2.tick()
+                        assert np.array_equal(e2.read_tick_actions(), want2) and np.array_equal(c2[1], want2_counts), step
                     act = e.read_tick_actions()
                     assert np.array_equal(act, want), (step, np.flatnonzero(act != want)[:8])
                     assert np.array_equal(counts, [np.count_nonzero(want & (1 << b)) for b in range(5)]), step
@@ -314,6 +336,7 @@ def test_random_call_sequences(oracle, S, G, seed):
                 assert np.array_equal(e.read_active(), sh["active"]), step
         assert checked[0] >= (25 if os.environ.get("RAFTHIP_FUZZ_ROUND", "0") == "0" else 10)  # the committed seeds check at least 25 calls each
         assert ticks >= 10
+        e2.close()
         assert np.array_equal(e.read_match(), sh["match"])
         assert np.array_equal(e.read_acks(), sh["acks"])
         assert np.array_equal(e.read_term_range()[1], sh["tl"])
