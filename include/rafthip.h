@@ -654,7 +654,7 @@ int rafthip_check_quorum(rafthip_engine *e);
  *   RAFTHIP_TICK_ABORT_TRANSFER  a leader's transfer did not finish within an election timeout
  *                                (raft.go:846-849); the flag is cleared
  *   RAFTHIP_TICK_BEAT            heartbeat_elapsed reached HeartbeatTick on a (still) leader: the host
- *                                steps MsgBeat -> bcastHeartbeat (rafthip_emit_heartbeats)
+ *                                steps MsgBeat -> bcastHeartbeat (rafthip_emit_heartbeats_due)
  * counts (may be NULL: nothing is copied back and the call does not wait):
  * counts[b] = groups whose action byte has bit b. */
 #define RAFTHIP_TICK_HUP 1u
@@ -686,7 +686,8 @@ int rafthip_tick_many(rafthip_engine *const *engines, uint32_t n, uint64_t *coun
  * heard from their leader since the last tick — MsgApp, MsgHeartbeat or MsgSnap
  * of the current term: election_elapsed of every listed group becomes 0.  A
  * list (host or device memory), not a plane: on a host that follows millions of
- * groups these are the ids its receive path has in hand anyway.  Duplicates are
+ * groups these are the ids its receive path has in hand anyway.  List followers
+ * only: the call resets the counter of whatever group it is given.  Duplicates are
  * fine; ids outside the engine are skipped and counted in *rejected (may be
  * NULL).  Waits for the GPU. */
 int rafthip_tick_heard_from_leader(rafthip_engine *e, const uint32_t *groups, uint64_t n, uint64_t *rejected);
