@@ -680,7 +680,8 @@ int rafthip_tick(rafthip_engine *e, uint64_t *counts);
  * planes, config and tick constants; counts (may be NULL) receives
  * RAFTHIP_TICK_ACTIONS words per engine.  Engines of one GPU and one mask width
  * share the launch (16 at a time); otherwise the call ticks them one by one.
- * Engines on different streams are joined as in rafthip_commit_many. */
+ * Engines on different streams are joined as in rafthip_commit_many.  An engine
+ * may appear in the list once only (its planes are written by the pass). */
 int rafthip_tick_many(rafthip_engine *const *engines, uint32_t n, uint64_t *counts);
 /* stepFollower's `r.electionElapsed = 0` (raft.go:1681-1692) for the groups that
  * heard from their leader since the last tick — MsgApp, MsgHeartbeat or MsgSnap

@@ -2880,6 +2880,9 @@ int rafthip_tick_many(rafthip_engine* const* engines, uint32_t n, uint64_t* coun
     if (!engines || n == 0) return fail(RAFTHIP_EINVAL, "engines is NULL or n is 0");
     for (u32 i = 0; i < n; ++i)
         if (!engines[i]) return fail(RAFTHIP_EINVAL, "engines[%u] is NULL", i);
+    for (u32 i = 1; i < n; ++i)
+        for (u32 j = 0; j < i; ++j)
+            if (engines[i] == engines[j]) return fail(RAFTHIP_EINVAL, "engines[%u] and engines[%u] are the same engine", j, i);
     rafthip_engine* e0 = engines[0];
     // one launch needs one GPU and one mask width; anything else is the per-engine pass, engine by engine
     bool same = true;

@@ -284,6 +284,7 @@ int main(void) {
             OK(rafthip_tick_many(two, 1, c2));
             OK(rafthip_tick_many(two, 1, NULL));
             FAILS(rafthip_tick_many(two, 0, NULL));
+            FAILS(rafthip_tick_many(two, 2, NULL)); /* the same engine twice */
             FAILS(rafthip_tick_many(NULL, 1, NULL));
         }
         OK(rafthip_tick(e, counts));
