@@ -69,3 +69,32 @@ def test_oracle_tick_against_the_statement_order(oracle, S, cq):
                                                         int(after[5][g]), int(act[g])), g
         # responses between ticks: some peers become active again
         t.load(active=after[5] | rng.integers(0, 1 << S, G).astype(mdt))
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_tick_shards_by_group_range_without_any_exchange(oracle, world):
+    """RawNode.Tick couples no two groups, so the multi-GPU form is the sharding of everything else (raft_amd/multigpu.py
+    shard_range): every rank ticks its own contiguous range and the concatenation is the one-engine result — state,
+    actions and the sum of the per-rank counts.  (One process here; the ranks' engines are independent by
+    construction, there is nothing to rendezvous on.)"""
+    from raft_amd import multigpu
+    rng = np.random.default_rng(50 + world)
+    G, S, et, ht = 10007, 5, 4, 2
+    whole = ts.OracleTicker(oracle, G, S, et, ht, True, uniform_voters=S)
+    init = dict(el=rng.integers(0, 2 * et, G), hb=rng.integers(0, ht + 1, G), rt=rng.integers(et, 2 * et, G),
+                role=rng.integers(0, 4, G), flags=rng.integers(0, 4, G), active=rng.integers(0, 1 << S, G).astype(np.uint8),
+                self_mask=(1 << rng.integers(0, S, G)).astype(np.uint8))
+    whole.load(**init)
+    ranks = []
+    for r in range(world):
+        first, count = multigpu.shard_range(G, r, world)
+        t = ts.OracleTicker(oracle, count, S, et, ht, True, uniform_voters=S)
+        t.load(**{k: np.asarray(v)[first:first + count] for k, v in init.items()})
+        ranks.append(t)
+    for _ in range(2 * et + 1):
+        act, counts = whole.tick()
+        parts = [t.tick() for t in ranks]
+        assert np.array_equal(np.concatenate([a for a, _ in parts]), act)
+        assert np.array_equal(sum(c for _, c in parts), counts)
+    for k, plane in enumerate(whole.state()):
+        assert np.array_equal(np.concatenate([t.state()[k] for t in ranks]), plane)
